@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (oracle/qatiger_oracle.py) against golden vectors that
+were produced by running the reference itself (tools/make_golden.py).  CPU only.
+The reference has no tests of its own, so these fixtures are the
+only pin: logits, loss, per-module intermediates, router choices, gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_cfg, rel_err, GOLDEN_CONFIGS
+
+TOL = 2e-5   # fp32 rounding-order noise between two CPU evaluation orders
+
+
+def _run(oracle, synth, name, fp64=False):
+    cfg, seed = golden_cfg(synth, name)
+    P = synth.make_state_dict(cfg, seed)
+    inp = synth.make_inputs(cfg, seed)
+    if fp64:
+        P = {n: t.double() for n, t in P.items()}
+        inp = {n: (t.double() if t.dtype.is_floating_point else t) for n, t in inp.items()}
+    taps = {}
+    loss, logits, grads = oracle.forward_backward(P, inp, cfg.K, cfg.k, taps=taps)
+    return cfg, P, inp, loss, logits, grads, taps
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CONFIGS))
+def test_recipe_regenerates_identically(synth, name):
+    g = load_golden(name)
+    cfg, seed = golden_cfg(synth, name)
+    assert list(cfg.asdict().values()) == g['cfg'].tolist()
+    P = synth.make_state_dict(cfg, seed)
+    inp = synth.make_inputs(cfg, seed)
+    w = sum(float(v.double().abs().sum()) for v in P.values())
+    i = sum(float(v.double().abs().sum()) for v in inp.values() if v.dtype.is_floating_point)
+    assert w == pytest.approx(float(g['weights_checksum']), rel=1e-12)
+    assert i == pytest.approx(float(g['inputs_checksum']), rel=1e-12)
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CONFIGS))
+def test_logits_loss_and_argmax(oracle, synth, name):
+    g = load_golden(name)
+    cfg, P, inp, loss, logits, grads, taps = _run(oracle, synth, name)
+    assert rel_err(logits.numpy(), g['logits']) < TOL
+    assert float(loss) == pytest.approx(float(g['loss']), rel=1e-5)
+    assert (logits.argmax(-1).numpy() == g['logits'].argmax(-1)).all()
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CONFIGS))
+def test_intermediates(oracle, synth, name):
+    g = load_golden(name)
+    *_, taps = _run(oracle, synth, name)
+    checked = 0
+    for key, ref in g.items():
+        if key.startswith('tap/'):
+            n = key[4:]
+            if n.endswith('gauss_raw'):
+                continue        # raw gauss_pred output is not tapped by the oracle
+            t = taps[n]
+            if n.endswith('topk_inds'):
+                assert (t.numpy() == ref).all(), n
+            else:
+                assert rel_err(t.detach().numpy().reshape(ref.shape), ref) < 5e-5, n
+            checked += 1
+        elif key.startswith('tapslice/'):
+            n = key[9:]
+            t = taps[n].detach().numpy().reshape(-1)
+            sl = t[:: max(1, t.size // 4096)][:4096]
+            assert rel_err(sl, ref) < 5e-5, n
+            s = g[f'tapsum/{n}']
+            assert np.allclose([t.mean(), np.abs(t).mean(), t.std()], s, rtol=1e-4, atol=1e-6), n
+            checked += 1
+    assert checked >= 10
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CONFIGS))
+def test_gradients(oracle, synth, name):
+    g = load_golden(name)
+    cfg, P, inp, loss, logits, grads, taps = _run(oracle, synth, name)
+    n_checked = 0
+    for n, gr in grads.items():
+        if f'grad/{n}' in g:
+            ref = g[f'grad/{n}']
+            scale = max(np.abs(ref).max(), 1e-8)
+            assert np.abs(gr.numpy() - ref).max() / scale < 2e-4, n
+        else:
+            ref_norm = float(g[f'gradnorm/{n}'])
+            nrm = float(gr.double().norm())
+            assert nrm == pytest.approx(ref_norm, rel=2e-4, abs=1e-9), n
+            flat = gr.numpy().reshape(-1)
+            sl = flat[:: max(1, flat.size // 256)][:256]
+            ref = g[f'gradslice/{n}']
+            assert np.abs(sl - ref).max() / max(np.abs(ref).max(), 1e-8) < 5e-4, n
+        n_checked += 1
+    assert n_checked == len(synth.param_shapes(cfg))
+    # every trainable parameter is reached (DDP find_unused_parameters=False,
+    # reference trainutils.py:103-106); with k<K unselected experts get exact zeros
+    if cfg.k == cfg.K:
+        assert all(float(gr.abs().max()) > 0 for gr in grads.values())
+
+
+def test_fp64_oracle_matches_fp32_golden(oracle, synth):
+    """fp32-vs-fp64 noise floor (~1e-6 abs on logits)."""
+    g = load_golden('toy')
+    *_, logits, grads, taps = _run(oracle, synth, 'toy', fp64=True)
+    assert rel_err(logits.numpy(), g['logits']) < 2e-5
+
+
+def test_tempmoe_known_answers(oracle):
+    """generate_gaussian / get_output vectors from the reference, incl. the
+    (b*T+t) % B expert-index rule with k<K, k=K, B>T and B not dividing T."""
+    g = load_golden('tempmoe_kats')
+    n = len([k for k in g if k.endswith('/shape')])
+    assert n >= 5
+    for ci in range(n):
+        B, T, C, K, k = g[f'kat{ci}/shape'].tolist()
+        pred = torch.from_numpy(g[f'kat{ci}/pred'])
+        ti = torch.from_numpy(g[f'kat{ci}/topk_inds'])
+        tp = torch.from_numpy(g[f'kat{ci}/topk_probs'])
+        gauss = oracle.generate_gaussian(pred, ti, T, K)
+        assert rel_err(gauss.numpy(), g[f'kat{ci}/gauss']) < 1e-5
+        eo = torch.from_numpy(g[f'kat{ci}/experts_out_TBKC']).permute(1, 0, 2, 3).contiguous()
+        out = oracle.moe_combine(eo, gauss, ti, tp)
+        assert rel_err(out.numpy(), g[f'kat{ci}/out']) < 1e-5
+
+
+def test_batch_composition_dependence(oracle, synth):
+    """Quirk Q1: the same samples evaluated in a different batch give different
+    logits, because expert choice of token (b,t) comes from sample (b*T+t) % B."""
+    cfg, seed = golden_cfg(synth, 'toy')
+    P = synth.make_state_dict(cfg, seed)
+    inp = synth.make_inputs(cfg, seed)
+    full = oracle.qa_tiger_forward(P, inp, cfg.K, cfg.k)
+    half = {n: t[:3] for n, t in inp.items()}
+    part = oracle.qa_tiger_forward(P, half, cfg.K, cfg.k)
+    assert float((full[:3] - part).abs().max()) > 1e-3
+
+
+def test_adam_matches_torch(oracle):
+    torch.manual_seed(0)
+    p0 = {'w': torch.randn(7, 5), 'b': torch.randn(5)}
+    ref = {n: t.clone().requires_grad_(True) for n, t in p0.items()}
+    opt = torch.optim.Adam(ref.values(), lr=1e-4, betas=(0.95, 0.999))
+    mine = {n: t.clone() for n, t in p0.items()}
+    m = {n: torch.zeros_like(t) for n, t in p0.items()}
+    v = {n: torch.zeros_like(t) for n, t in p0.items()}
+    for step in range(1, 4):
+        grads = {n: torch.randn_like(t) for n, t in p0.items()}
+        for n in ref:
+            ref[n].grad = grads[n].clone()
+        opt.step()
+        oracle.adam_step(mine, grads, m, v, step)
+        for n in ref:
+            assert torch.allclose(mine[n], ref[n].detach(), atol=1e-7, rtol=1e-6)

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (CPU, eval mode).
+
+Runs only in the build container (it needs /root/reference, which does not
+travel to the GPU box); nothing in tests/, bench.py or the package imports this
+file.  It contains no reference code: it imports `src.models.net.QA_TIGER` from
+/root/reference, replaces the un-importable text tower (`src.models.encoders`
+needs torchvision/ftfy and downloads a checkpoint — SURVEY.md §8c) with a stub
+that returns injected `(quest, words)` features, loads the repo's recipe
+weights (qa-tiger_amd/synth.py) with `load_state_dict`, and records inputs-free
+fixtures: logits, loss, per-module intermediates, router diagnostics, gradients.
+
+    python tools/make_golden.py            # writes tests/golden/
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REPO)
+synth = importlib.import_module('qa-tiger_amd.synth')
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    stub = types.ModuleType('src.models.encoders')
+
+    class CLIP_TEncoder(nn.Module):           # stand-in for reference encoders.py:7-37
+        def __init__(self, name):
+            super().__init__()
+            self.quest, self.words = None, None
+
+        def freeze(self):
+            pass
+
+        def forward(self, tokens):
+            return self.quest, self.words
+
+    stub.CLIP_TEncoder = CLIP_TEncoder
+    import src.models  # noqa: F401  (reference package)
+    sys.modules['src.models.encoders'] = stub
+    from src.models import net, modules
+    return net, modules
+
+
+def build_reference_model(net, cfg, seed):
+    model = net.QA_TIGER(**cfg.model_kwargs())
+    sd = synth.make_state_dict(cfg, seed)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    assert not msg.missing_keys, msg.missing_keys   # stub encoder has no params
+    model.eval()
+    return model, sd
+
+
+def run_reference(net, cfg, seed, keep_grads='all'):
+    torch.manual_seed(0)
+    model, sd = build_reference_model(net, cfg, seed)
+    inp = synth.make_inputs(cfg, seed)
+    model.quest_encoder.quest = inp['quest_feat']
+    model.quest_encoder.words = inp['words_feat']
+    taps = {}
+
+    def hook(name):
+        def fn(mod, args, out):
+            if isinstance(out, (tuple, list)):
+                for i, o in enumerate(out):
+                    if isinstance(o, torch.Tensor):
+                        taps[f'{name}.{i}'] = o.detach().clone()
+            else:
+                taps[name] = out.detach().clone()
+        return fn
+
+    for name in ('crs_attn', 'patch_selecter', 'at_aggregator', 'vt_aggregator',
+                 'at_aggregator.router', 'vt_aggregator.router',
+                 'at_aggregator.gauss_pred', 'vt_aggregator.gauss_pred'):
+        model.get_submodule(name).register_forward_hook(hook(name))
+    # quest_grounding is called twice with shared weights (net.py:136,138)
+    calls = []
+    model.quest_grounding.register_forward_hook(lambda m, a, o: calls.append(o.detach().clone()))
+    # temp_w = output 0 of TempMoE.qst_attn
+    for agg in ('at_aggregator', 'vt_aggregator'):
+        model.get_submodule(f'{agg}.qst_attn').register_forward_hook(hook(f'{agg}.qst_attn'))
+        mod = model.get_submodule(agg)
+        orig_gg, orig_go = mod.generate_gaussian, mod.get_output
+
+        def gg(pred, topk_inds, T=60, _o=orig_gg, _a=agg):
+            out = _o(pred, topk_inds=topk_inds, T=T)
+            taps[f'{_a}.topk_inds'] = topk_inds.detach().clone()
+            taps[f'{_a}.gauss'] = out.detach().clone()
+            return out
+
+        def go(el, gw, ti, tp, shape, _o=orig_go, _a=agg):
+            taps[f'{_a}.topk_probs'] = tp.detach().clone()
+            return _o(el, gw, ti, tp, shape)
+
+        mod.generate_gaussian, mod.get_output = gg, go
+
+    data = dict(quest=torch.zeros(cfg.B, cfg.L, dtype=torch.int32),   # int tokens -> encoder path (net.py:98-101)
+                audio=inp['audio'], video=inp['video'], patch=inp['patch'])
+    out = model(data)['out']
+    loss = nn.CrossEntropyLoss()(out, inp['label'])                    # train.py:41, trainutils.py:278
+    loss.backward()
+
+    rec = {'logits': out.detach().numpy(), 'loss': np.float64(loss.item()),
+           'cfg': np.array(list(cfg.asdict().values()), dtype=np.int64),
+           'seed': np.int64(seed)}
+    names = {'crs_attn.0': 'crs_attn.audio', 'crs_attn.1': 'crs_attn.video',
+             'patch_selecter.0': 'patch_selecter.a', 'patch_selecter.1': 'patch_selecter.v',
+             'at_aggregator': 'at_aggregator.out', 'vt_aggregator.0': 'vt_aggregator.a_out',
+             'vt_aggregator.1': 'vt_aggregator.v_out',
+             'at_aggregator.router': 'at_aggregator.router_logits',
+             'vt_aggregator.router': 'vt_aggregator.router_logits',
+             'at_aggregator.gauss_pred': 'at_aggregator.gauss_raw',
+             'vt_aggregator.gauss_pred': 'vt_aggregator.gauss_raw'}
+    for agg in ('at_aggregator', 'vt_aggregator'):
+        taps[f'{agg}.temp_w'] = taps.pop(f'{agg}.qst_attn.0')[0]
+        taps.pop(f'{agg}.qst_attn.1', None)
+        for s in ('topk_inds', 'topk_probs', 'gauss'):
+            names[f'{agg}.{s}'] = f'{agg}.{s}'
+        names[f'{agg}.temp_w'] = f'{agg}.temp_w'
+    taps['quest_grounding.1'], taps['quest_grounding.2'] = calls
+    names['quest_grounding.1'] = 'quest_grounding.1'
+    names['quest_grounding.2'] = 'quest_grounding.2'
+    big = cfg.D > 128
+    for src, dst in names.items():
+        t = taps[src].numpy()
+        if big and t.size > 65536:            # summarise large activations
+            rec[f'tapsum/{dst}'] = np.array([t.mean(), np.abs(t).mean(), t.std()], dtype=np.float64)
+            rec[f'tapslice/{dst}'] = t.reshape(-1)[:: max(1, t.size // 4096)][:4096].copy()
+        else:
+            rec[f'tap/{dst}'] = t
+    for agg in ('at_aggregator', 'vt_aggregator'):
+        rl = taps[f'{agg}.router']
+        s = torch.sort(rl, dim=-1, descending=True)[0]
+        rec[f'router_gap/{agg}'] = np.float64((s[:, :-1] - s[:, 1:]).min().item())
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.startswith('quest_encoder'):
+            continue
+        g = p.grad.detach().numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        if keep_grads == 'all':
+            rec[f'grad/{n}'] = g
+        else:
+            rec[f'gradnorm/{n}'] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            rec[f'gradslice/{n}'] = g.reshape(-1)[:: max(1, g.size // 256)][:256].copy()
+    # checksum of the recipe weights so every consumer can verify regeneration
+    rec['weights_checksum'] = np.float64(sum(float(v.double().abs().sum()) for v in sd.values()))
+    rec['inputs_checksum'] = np.float64(sum(float(v.double().abs().sum()) for k_, v in inp.items()
+                                            if v.dtype.is_floating_point))
+    return rec
+
+
+def block_kats(modules):
+    """Known-answer vectors for the two index-heavy TempMoE helpers, at shapes
+    that pin the modulo rule: k<K, k=K, B not dividing T, B>T."""
+    rec = {}
+    cases = [(4, 10, 16, 4, 4), (5, 7, 8, 6, 3), (16, 6, 8, 8, 8), (3, 60, 12, 8, 8), (7, 5, 8, 5, 2)]
+    for ci, (B, T, C, K, k) in enumerate(cases):
+        g = torch.Generator().manual_seed(1000 + ci)
+        moe = modules.TempMoE(d_model=16, nhead=8, topK=k, n_experts=K)
+        raw = torch.randn(B, K, 2, generator=g)
+        pred = torch.stack([torch.tanh(raw[..., 0]) * moe.margin, torch.sigmoid(raw[..., 1] * 3)], -1)
+        probs = torch.softmax(torch.randn(B, K, generator=g), -1)
+        tp, ti = torch.topk(probs, k, dim=-1)
+        tp = tp / tp.sum(-1, keepdim=True)
+        gauss = moe.generate_gaussian(pred, topk_inds=ti, T=T)
+        experts_out = torch.randn(T, B, K, C, generator=g)
+        out = moe.get_output(experts_out, gauss, ti, tp, (B, T, C))
+        rec[f'kat{ci}/shape'] = np.array([B, T, C, K, k], dtype=np.int64)
+        rec[f'kat{ci}/pred'] = pred.numpy()
+        rec[f'kat{ci}/topk_inds'] = ti.numpy()
+        rec[f'kat{ci}/topk_probs'] = tp.numpy()
+        rec[f'kat{ci}/gauss'] = gauss.numpy()
+        rec[f'kat{ci}/experts_out_TBKC'] = experts_out.numpy()
+        rec[f'kat{ci}/out'] = out.numpy()
+    return rec
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    net, modules = import_reference()
+    np.savez_compressed(os.path.join(OUT, 'tempmoe_kats.npz'), **block_kats(modules))
+    jobs = [('toy', synth.CONFIG_TOY, 713, 'all'),
+            ('toy_kk', synth.CONFIG_TOY_KK, 11, 'all'),
+            ('config1', synth.CONFIG_1, 713, 'summary'),
+            ('config2_b8', synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 8}), 713, 'summary')]
+    for name, cfg, seed, kg in jobs:
+        rec = run_reference(net, cfg, seed, keep_grads=kg)
+        path = os.path.join(OUT, f'{name}.npz')
+        np.savez_compressed(path, **rec)
+        print(f'{name}: loss={float(rec["loss"]):.6f} max|logit|={np.abs(rec["logits"]).max():.4f} '
+              f'gaps={float(rec["router_gap/at_aggregator"]):.2e}/{float(rec["router_gap/vt_aggregator"]):.2e} '
+              f'-> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+if __name__ == '__main__':
+    main()
