@@ -1,0 +1,120 @@
+/* libqatiger_hip.so — C ABI of the MI355X (gfx950) kernels behind the QA-TIGER
+ * fusion path.
+ *
+ * The reference (FightSH/QA-TIGER) has no FFI or operator-plugin API: its hot
+ * path is `QA_TIGER.forward` (src/models/net.py:106-144) composed of torch.nn
+ * modules (src/models/modules.py).  The drop-in boundary is therefore the
+ * nn.Module surface (mirrored in qa-tiger_amd/src/models/), and this header is
+ * the native layer underneath it: each entry point replaces the ATen op group
+ * named in its comment.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch): the
+ *    library never allocates, frees or synchronises, and keeps no global state;
+ *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); all
+ *    work is enqueued on it, so the calls are hipGraph-capturable;
+ *  - tensors are row-major fp32 with explicit leading dimensions (in elements);
+ *  - return 0 on success, <0 on error (-2 bad argument, -3 launch failure,
+ *    -4 unsupported shape); `qt_last_error()` returns a thread-local message;
+ *  - dropout masks come from a stateless counter RNG keyed by (seed, element
+ *    index): passing the same seed to the backward call regenerates the mask.
+ */
+#ifndef QATIGER_H
+#define QATIGER_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int qt_version(void);
+const char* qt_last_error(void);
+
+/* C[M,N] = epilogue(alpha * op(A) op(B)).
+ * Replaces nn.Linear / packed MHA in- and out-projections: modules.py:33,43
+ * (Projection), 174-182 (AVQCrossAttn MHAs, linear1/2), 284-290, 382-398,
+ * 637-645; net.py:60 (head); and their autograd backward.
+ *   transA=0: A is [M,K] (lda>=K)   transA=1: A is [K,M] (lda>=M)
+ *   transB=1: B is [N,K] (Linear weight layout)   transB=0: B is [K,N]
+ * epilogue order: +bias[n], +add_src[m,n], relu, mask (mask_src[m,n]>0 ? v*mask_scale : 0),
+ * dropout(drop_p, drop_seed, element index m*N+n), accumulate (C += v).
+ * split_k: 0 = auto, 1 = off, >1 = K split over workgroups with fp32 atomics
+ * (linear epilogues only). */
+int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                const float* bias, const float* add_src, long ld_add, int relu,
+                const float* mask_src, long ld_mask, float mask_scale,
+                float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
+
+/* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
+ * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward
+ * math path) at modules.py:217-221, 338, 562, 688, 698.
+ * Element (item n, row i, col c) of q is q[(n*q_is + i*q_rs)*ldq + c]; key/value rows
+ * of kv item m are rows m*kv_is .. m*kv_is+Lk-1.  Query item n attends to kv item
+ * (n + kv_shift) % n_kv.  Head h uses columns h*dh .. h*dh+dh-1. */
+int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                const float* k, long ldk, const float* v, long ldv, long kv_is,
+                float* o, long ldo, long o_is, long o_rs,
+                int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                float scale, float drop_p, unsigned long long seed);
+int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                const float* k, long ldk, const float* v, long ldv, long kv_is,
+                const float* d_o, long lddo, long do_is, long do_rs,
+                float* dq, long lddq, long dq_is, long dq_rs,
+                float* dk, long lddk, float* dv, long lddv,
+                int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                float scale, float drop_p, unsigned long long seed);
+
+/* y = LayerNorm(sum_i sx[i] * dropout_i(x[i])) (+ optional ReLU on y); n_add <= 4.
+ * Replaces modules.py:223-229, 233-235, 344-346, 603, 612, 713-716.
+ * x, ldx, sx, drop, seed, dx, lddx, dx_acc are HOST arrays of length n_add.
+ * xhat [rows,D] and rstd [rows] are saved for the backward. */
+int qt_add_ln_fwd(void* stream, int rows, int D, int n_add,
+                  const float* const* x, const long* ldx, const float* sx, const int* drop,
+                  const unsigned long long* seed, float drop_p,
+                  const float* gamma, const float* beta, float eps,
+                  float* y, long ldy, int relu_out, float* xhat, float* rstd);
+int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
+                  const float* dy, long lddy, const float* xhat, const float* rstd, const float* gamma,
+                  const float* sx, const int* drop, const unsigned long long* seed, float drop_p,
+                  float* const* dx, const long* lddx, const int* dx_acc,
+                  float* dgamma, float* dbeta);
+
+/* TempMoE router / Gaussian weights (modules.py:565-580, 420-471):
+ * logits [B,K], gauss_raw [B,2K] (pairs (u_e, v_e)) -> probs [B,K], topk_inds [B,k] int64
+ * (sorted by descending probability), topk_probs [B,k] (renormalised), gauss [B,k,T]. */
+int qt_moe_router_fwd(void* stream, const float* logits, const float* gauss_raw, int B, int T, int K, int k,
+                      float* probs, long long* topk_inds, float* topk_probs, float* gauss);
+/* coef[b,t,e] = sum_i [topk_inds[(b*T+t)%B, i]==e] topk_probs[b,i] gauss[b,i,t]; csum[b,e] = sum_t coef
+ * (modules.py:495-533 including the repeat(T,1) index rule). */
+int qt_moe_coef_fwd(void* stream, const long long* topk_inds, const float* topk_probs, const float* gauss,
+                    int B, int T, int K, int k, float* coef, float* csum);
+/* R[s*B+b, e, :] = sum_t coef[b,t,e] * H[(s*B+b)*T+t, e, :]   (H = expert first-layer activations
+ * [S*B*T, K*Dh]; modules.py:590-599 + 517-533 with the second layer pulled out of the sum). */
+int qt_moe_treduce_fwd(void* stream, const float* H, const float* coef, int S, int B, int T, int K, int Dh, float* R);
+int qt_moe_treduce_bwd(void* stream, const float* H, const float* coef, const float* dR,
+                       int S, int B, int T, int K, int Dh, float* dH, float* dcoef);
+/* dcsum (nullable) is the gradient of csum; it is folded into dcoef on the fly. */
+int qt_moe_router_bwd(void* stream, const float* dcoef, const long long* topk_inds, const float* topk_probs,
+                      const float* gauss, const float* probs, const float* gauss_raw, const float* dcsum,
+                      int B, int T, int K, int k, float* dlogits, float* dgauss_raw);
+
+/* out[n] (+)= sum_m x[m,n]  — bias gradients of every nn.Linear. */
+int qt_colsum(void* stream, const float* x, long ldx, int M, int N, float* out, int accumulate);
+/* out[r,:] = alpha*a[r % ra,:] + beta*b[r % rb,:]  — `data + sub_data` (modules.py:587,596) and gradient folds. */
+int qt_add_rows(void* stream, const float* a, long lda, int ra, float alpha,
+                const float* b, long ldb, int rb, float beta, float* out, long ldo, long rows, int D);
+/* out = g * mask: y given -> (y>0 ? 1/(1-p) : 0)  [backward of dropout(relu(z)) from its output];
+ * y null -> the forward dropout multiplier regenerated from (seed, r*N+c). */
+int qt_mask_grad(void* stream, const float* g, long ldg, const float* y, long ldy, float drop_p,
+                 unsigned long long seed, float* out, long ldo, long rows, int N);
+/* nn.CrossEntropyLoss(mean) and d loss / d logits (train.py:41, trainutils.py:278,286). */
+int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long* label, int B, int A,
+                    float* loss_rows, float* loss_mean, float* dlogits, long ldd);
+/* torch.optim.Adam (weight_decay 0) on one flat buffer (trainutils.py:141-144);
+ * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce). */
+int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                 int step, float lr, float beta1, float beta2, float eps, float grad_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QATIGER_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libqatiger_hip.so (declared in include/qatiger.h).
+
+No CPU fallback exists: if the shared library is missing or a kernel call
+fails, the caller gets an exception (SURVEY.md §8b "errors: plain Python
+exceptions").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
+SOURCES = ['gemm.hip', 'attn.hip', 'norm.hip', 'moe.hip', 'misc.hip']
+GFX = 'gfx950'
+
+
+class QTError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP kernels for gfx950 into one in-tree shared library."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'qt_common.h')]
+    if not force and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '-O3', f'--offload-arch={GFX}', '-fPIC', '-shared', '-std=c++17',
+           '-Wno-unused-result', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise QTError(f'hipcc failed:\n{res.stdout}\n{res.stderr}')
+    return LIB_PATH
+
+
+_p = C.c_void_p
+_i, _l, _f, _u64 = C.c_int, C.c_long, C.c_float, C.c_ulonglong
+
+# name -> argtypes; every function returns int (0 = ok) except the two noted
+SIGNATURES = {
+    'qt_gemm_f32': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
+    'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64],
+    'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
+                    _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64],
+    'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],
+    'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
+    'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
+    'qt_moe_coef_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    'qt_moe_treduce_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'qt_moe_treduce_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    'qt_moe_router_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    'qt_colsum': [_p, _p, _l, _i, _i, _p, _i],
+    'qt_add_rows': [_p, _p, _l, _i, _f, _p, _l, _i, _f, _p, _l, _l, _i],
+    'qt_mask_grad': [_p, _p, _l, _p, _l, _f, _u64, _p, _l, _l, _i],
+    'qt_xent_fwd_bwd': [_p, _p, _l, _p, _i, _i, _p, _p, _p, _l],
+    'qt_adam_step': [_p, _p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f],
+}
+EXPORTS = ['qt_version', 'qt_last_error'] + list(SIGNATURES)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load (building first if the .so is absent and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        try:
+            build()
+        except Exception as e:  # noqa: BLE001
+            raise QTError(f'{LIB_PATH} is missing and could not be built ({e}); '
+                          'run `python -c "import __graft_entry__ as g; g.build()"`') from e
+    lib = C.CDLL(LIB_PATH)
+    lib.qt_version.restype = C.c_int
+    lib.qt_last_error.restype = C.c_char_p
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().qt_last_error().decode(errors='replace')
+        raise QTError(f'{what} failed (code {rc}): {msg}')

@@ -1,0 +1,196 @@
+// Small HBM-bound helpers of the train step (fp32):
+//   qt_colsum          bias gradients  db[n] = Σ_m dY[m,n]              (backward of every nn.Linear bias)
+//   qt_add_rows        out[r,:] = a[r % ra,:] + b[r,:]                   (TempMoE `data + sub_data`, reference modules.py:587,596)
+//   qt_xent_fwd_bwd    nn.CrossEntropyLoss(mean) + its gradient          (reference train.py:41, trainutils.py:278)
+//   qt_adam_step       torch.optim.Adam on one flat buffer               (reference trainutils.py:141-144)
+//   qt_version / qt_last_error
+#include "qt_common.h"
+#include <math.h>
+
+thread_local char qt_err_buf[512] = "";
+
+extern "C" int qt_version(void) { return 100; }   // 0.1.0
+extern "C" const char* qt_last_error(void) { return qt_err_buf; }
+
+// ---- column sums ---------------------------------------------------------------
+// grid = (ceil(N/256), row_chunks); each thread owns one column of its chunk:
+// consecutive lanes read consecutive columns (coalesced), partials meet in atomics.
+__global__ __launch_bounds__(256) void qt_colsum_kernel(const float* __restrict__ x, long ldx, int M, int N,
+                                                        int rows_per_chunk, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m_beg = blockIdx.y * rows_per_chunk;
+    const int m_end = min(M, m_beg + rows_per_chunk);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m_beg;
+    for (; m + 3 < m_end; m += 4) {
+        s0 += x[(long)(m + 0) * ldx + n]; s1 += x[(long)(m + 1) * ldx + n];
+        s2 += x[(long)(m + 2) * ldx + n]; s3 += x[(long)(m + 3) * ldx + n];
+    }
+    for (; m < m_end; ++m) s0 += x[(long)m * ldx + n];
+    atomicAdd(out + n, (s0 + s1) + (s2 + s3));
+}
+
+extern "C" int qt_colsum(void* stream, const float* x, long ldx, int M, int N, float* out, int accumulate) {
+    QT_CHECK_ARG(x && out && M > 0 && N > 0 && ldx >= N, "qt_colsum: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_colsum: memset: %s", hipGetErrorString(e));
+    }
+    const int col_blocks = (N + 255) / 256;
+    int chunks = (2048 + col_blocks - 1) / col_blocks;        // ~2048 workgroups in flight
+    if (chunks > (M + 63) / 64) chunks = (M + 63) / 64;
+    if (chunks < 1) chunks = 1;
+    const int rpc = (M + chunks - 1) / chunks;
+    chunks = (M + rpc - 1) / rpc;
+    hipLaunchKernelGGL(qt_colsum_kernel, dim3(col_blocks, chunks), dim3(256), 0, st, x, ldx, M, N, rpc, out);
+    QT_CHECK_LAUNCH("qt_colsum");
+    return QT_OK;
+}
+
+// ---- out[r,:] = alpha*a[r % ra,:] + beta*b[r % rb,:] ----------------------------------
+__global__ __launch_bounds__(256) void qt_add_rows_kernel(const float* __restrict__ a, long lda, int ra, float alpha,
+                                                          const float* __restrict__ b, long ldb, int rb, float beta,
+                                                          float* __restrict__ out, long ldo, long rows, int nv) {
+    const long total = rows * nv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / nv; const int c4 = (int)(idx - r * nv);
+        const float4 x = *reinterpret_cast<const float4*>(a + (r % ra) * lda + c4 * 4);
+        const float4 y = *reinterpret_cast<const float4*>(b + (r % rb) * ldb + c4 * 4);
+        float4 o = make_float4(alpha * x.x + beta * y.x, alpha * x.y + beta * y.y, alpha * x.z + beta * y.z, alpha * x.w + beta * y.w);
+        *reinterpret_cast<float4*>(out + r * ldo + c4 * 4) = o;
+    }
+}
+
+extern "C" int qt_add_rows(void* stream, const float* a, long lda, int ra, float alpha,
+                           const float* b, long ldb, int rb, float beta,
+                           float* out, long ldo, long rows, int D) {
+    QT_CHECK_ARG(a && b && out && rows > 0 && D > 0 && ra > 0 && rb > 0, "qt_add_rows: bad arguments");
+    QT_CHECK_ARG(D % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0 && qt_aligned16(a) && qt_aligned16(b) && qt_aligned16(out),
+                 "qt_add_rows: rows must be 16-byte aligned (D=%d)", D);
+    const int nv = D / 4;
+    long blocks = (rows * nv + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(qt_add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       a, lda, ra, alpha, b, ldb, rb, beta, out, ldo, rows, nv);
+    QT_CHECK_LAUNCH("qt_add_rows");
+    return QT_OK;
+}
+
+// ---- gradient masking for y = dropout(relu(z)) / dropout(z) --------------------------------
+// y given : out = g * (y > 0 ? inv_keep : 0)      (y>0 <=> relu passed AND element kept)
+// y null  : out = g * dropout_multiplier(seed, r*N + c)   (same index space as the forward epilogue)
+__global__ __launch_bounds__(256) void qt_mask_grad_kernel(const float* __restrict__ g, long ldg, const float* __restrict__ y, long ldy,
+                                                           float drop_p, float inv_keep, unsigned long long seed,
+                                                           float* __restrict__ out, long ldo, long rows, int N) {
+    const long total = rows * N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / N; const int c = (int)(idx - r * N);
+        float m;
+        if (y) m = y[r * ldy + c] > 0.f ? inv_keep : 0.f;
+        else   m = qt_drop_mult(seed, (unsigned long long)idx, drop_p, inv_keep);
+        out[r * ldo + c] = g[r * ldg + c] * m;
+    }
+}
+
+extern "C" int qt_mask_grad(void* stream, const float* g, long ldg, const float* y, long ldy, float drop_p,
+                            unsigned long long seed, float* out, long ldo, long rows, int N) {
+    QT_CHECK_ARG(g && out && rows > 0 && N > 0, "qt_mask_grad: bad arguments");
+    QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_mask_grad: drop_p=%f", drop_p);
+    QT_CHECK_ARG(y || drop_p > 0.f, "qt_mask_grad: nothing to mask");
+    long blocks = (rows * N + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(qt_mask_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       g, ldg, y, ldy, drop_p, 1.0f / (1.0f - drop_p), seed, out, ldo, rows, N);
+    QT_CHECK_LAUNCH("qt_mask_grad");
+    return QT_OK;
+}
+
+// ---- softmax cross-entropy, mean reduction: loss and dlogits in one pass ---------------
+// one wavefront per sample (A = 42 classes fits one wave; larger A strides)
+__global__ __launch_bounds__(256) void qt_xent_kernel(const float* __restrict__ logits, long ld, const long long* __restrict__ label,
+                                                      int B, int A, float grad_scale, float* __restrict__ loss_rows,
+                                                      float* __restrict__ dlogits, long ldd) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* row = logits + (long)b * ld;
+    float mx = -INFINITY;
+    for (int a = lane; a < A; a += 64) mx = fmaxf(mx, row[a]);
+    mx = qt_wave_max(mx);
+    float sum = 0.f;
+    for (int a = lane; a < A; a += 64) sum += expf(row[a] - mx);
+    sum = qt_wave_sum(sum);
+    const int y = (int)label[b];
+    if (lane == 0) loss_rows[b] = (y >= 0 && y < A) ? (logf(sum) + mx - row[y]) : NAN;   // out-of-range label: loud NaN
+    if (dlogits) {
+        const float inv = 1.0f / sum;
+        for (int a = lane; a < A; a += 64)
+            dlogits[(long)b * ldd + a] = grad_scale * (expf(row[a] - mx) * inv - (a == y ? 1.f : 0.f));
+    }
+}
+// fixed-order mean of the per-sample losses (single wave; B is a few hundred)
+__global__ __launch_bounds__(64) void qt_mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += x[i];
+    s = qt_wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+extern "C" int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long* label, int B, int A,
+                               float* loss_rows, float* loss_mean, float* dlogits, long ldd) {
+    QT_CHECK_ARG(logits && label && loss_rows && loss_mean && B > 0 && A > 0, "qt_xent_fwd_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(qt_xent_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, ld, label, B, A, 1.0f / (float)B,
+                       loss_rows, dlogits, ldd);
+    QT_CHECK_LAUNCH("qt_xent");
+    hipLaunchKernelGGL(qt_mean_kernel, dim3(1), dim3(64), 0, st, loss_rows, B, loss_mean);
+    QT_CHECK_LAUNCH("qt_mean");
+    return QT_OK;
+}
+
+// ---- Adam on a flat buffer (weight_decay 0; bias-corrected exactly as torch.optim.Adam) --
+__global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                      float bc1, float bc2_sqrt, float grad_scale) {
+    const long nv = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define QT_ADAM1(c)                                                              \
+        { const float gr = gg.c * grad_scale;                                     \
+          mm.c = b1 * mm.c + (1.f - b1) * gr;                                      \
+          vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                                 \
+          pp.c -= (lr / bc1) * mm.c / (sqrtf(vv.c) / bc2_sqrt + eps); }
+        QT_ADAM1(x) QT_ADAM1(y) QT_ADAM1(z) QT_ADAM1(w)
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {          // tail
+        const long i = (nv << 2) + threadIdx.x;
+        const float gr = g[i] * grad_scale;
+        m[i] = b1 * m[i] + (1.f - b1) * gr;
+        v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+    }
+}
+
+extern "C" int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                            int step, float lr, float beta1, float beta2, float eps, float grad_scale) {
+    QT_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "qt_adam_step: bad arguments");
+    QT_CHECK_ARG(qt_aligned16(param) && qt_aligned16(grad) && qt_aligned16(exp_avg) && qt_aligned16(exp_avg_sq),
+                 "qt_adam_step: flat buffers must be 16-byte aligned");
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(qt_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+    QT_CHECK_LAUNCH("qt_adam_step");
+    return QT_OK;
+}

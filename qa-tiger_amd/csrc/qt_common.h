@@ -1,0 +1,58 @@
+// Shared device/host helpers for libqatiger_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define QT_WAVE 64
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- error reporting (thread-local, read through qt_last_error()) ----------
+extern thread_local char qt_err_buf[512];
+#define QT_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(qt_err_buf, sizeof(qt_err_buf), __VA_ARGS__); \
+        return (code);                                       \
+    } while (0)
+#define QT_CHECK_ARG(cond, ...) \
+    do { if (!(cond)) QT_FAIL(-2, __VA_ARGS__); } while (0)
+#define QT_CHECK_LAUNCH(name)                                                  \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) QT_FAIL(-3, "%s launch: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+enum { QT_OK = 0, QT_ERR_RUNTIME = -1, QT_ERR_ARG = -2, QT_ERR_LAUNCH = -3, QT_ERR_UNSUPPORTED = -4 };
+
+// ---- counter-based dropout RNG ---------------------------------------------
+// splitmix64 finaliser over (seed, element index): stateless, so the backward
+// kernels regenerate the forward mask from the same (seed, index).
+__host__ __device__ inline uint32_t qt_rand_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+// keep-probability 1-p; returns the inverted-dropout multiplier (0 or 1/(1-p))
+__host__ __device__ inline float qt_drop_mult(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    const float u = (float)(qt_rand_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.0f;
+}
+
+// ---- wave reductions (64 lanes) ---------------------------------------------
+__device__ inline float qt_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float qt_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline bool qt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,444 @@
+"""Host-side operators of the QA-TIGER fusion path: thin wrappers that hand raw
+device pointers to libqatiger_hip.so, and the `torch.autograd.Function`s built on
+them.  PyTorch supplies device memory, the current HIP stream and the autograd
+graph; every FLOP runs in the hand-written kernels.  There is no CPU fallback:
+a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+LN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------- #
+# plumbing
+# --------------------------------------------------------------------------- #
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[C.c_void_p]:
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.QTError('qa-tiger_amd kernels need tensors on an MI355X (cuda) device; got a '
+                               f'{t.device.type} tensor and there is no CPU fallback')
+        if t.dtype != torch.float32:
+            raise _lib.QTError(f'fp32 tensor expected, got {t.dtype}')
+
+
+def as2d(t: Tensor) -> Tensor:
+    """View as [rows, cols] with unit column stride (copy only if unavoidable)."""
+    if t.dim() != 2:
+        t = t.reshape(-1, t.shape[-1])
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+class _Seeds:
+    """Dropout seeds: one fresh 64-bit value per dropout site per call, derived
+    from torch's seed so `torch.manual_seed` makes runs repeatable."""
+
+    def __init__(self):
+        self.base = None
+        self.count = 0
+
+    def next(self) -> int:
+        if self.base is None:
+            self.base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        self.count += 1
+        return (self.base * 0x9E3779B97F4A7C15 + self.count * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF
+
+    def reset(self, base: Optional[int] = None):
+        self.base, self.count = base, 0
+
+
+seeds = _Seeds()
+
+
+# --------------------------------------------------------------------------- #
+# raw kernel calls (no autograd)
+# --------------------------------------------------------------------------- #
+def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, out: Optional[Tensor] = None,
+         bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: bool = False,
+         mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
+         accumulate: bool = False, alpha: float = 1.0, split_k: int = 0) -> Tensor:
+    """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32."""
+    a, b = as2d(a), as2d(b)
+    _dev(a, b, bias, add, mask_src, out)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    if K != Kb:
+        raise _lib.QTError(f'gemm: inner dimensions differ ({K} vs {Kb})')
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    else:
+        out = out if out.dim() == 2 else out.reshape(-1, out.shape[-1])
+        assert out.shape == (M, N) and out.stride(1) == 1
+    if add is not None:
+        add = as2d(add)
+        assert add.shape == (M, N)
+    if mask_src is not None:
+        mask_src = as2d(mask_src)
+        assert mask_src.shape == (M, N)
+    rc = _lib.load().qt_gemm_f32(
+        _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
+        _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
+        _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
+        _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k))
+    _lib.check(rc, 'qt_gemm_f32')
+    return out
+
+
+def colsum(x: Tensor) -> Tensor:
+    x = as2d(x)
+    _dev(x)
+    out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().qt_colsum(_stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), 0), 'qt_colsum')
+    return out
+
+
+def add_rows(a: Tensor, b: Tensor, alpha: float = 1.0, beta: float = 1.0, rows: Optional[int] = None) -> Tensor:
+    """out[r] = alpha*a[r % rows(a)] + beta*b[r % rows(b)]."""
+    a, b = as2d(a), as2d(b)
+    _dev(a, b)
+    rows = max(a.shape[0], b.shape[0]) if rows is None else rows
+    D = a.shape[1]
+    out = torch.empty((rows, D), device=a.device, dtype=torch.float32)
+    rc = _lib.load().qt_add_rows(_stream(), _ptr(a), _ld(a), a.shape[0], float(alpha), _ptr(b), _ld(b), b.shape[0],
+                                 float(beta), _ptr(out), D, rows, D)
+    _lib.check(rc, 'qt_add_rows')
+    return out
+
+
+def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int) -> Tensor:
+    g = as2d(g)
+    _dev(g, y)
+    out = torch.empty_like(g, memory_format=torch.contiguous_format)
+    if y is not None:
+        y = as2d(y)
+    rc = _lib.load().qt_mask_grad(_stream(), _ptr(g), _ld(g), _ptr(y), _ld(y) if y is not None else 0, float(drop_p),
+                                  C.c_ulonglong(seed), _ptr(out), _ld(out), g.shape[0], g.shape[1])
+    _lib.check(rc, 'qt_mask_grad')
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# Linear:  y = dropout(relu(x W^T + b))        (reference nn.Linear call sites)
+# --------------------------------------------------------------------------- #
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, drop_p: float, seed: int,
+                residual: Optional[Tensor], grad_premasked: bool):
+        shape = x.shape
+        x2 = as2d(x)
+        y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.cfg = (relu, drop_p, seed, bias is not None, residual is not None, grad_premasked, shape)
+        return y.reshape(*shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x2, weight, y = ctx.saved_tensors
+        relu, drop_p, seed, has_bias, has_res, premasked, shape = ctx.cfg
+        g = as2d(dy)
+        if (relu or drop_p > 0.0) and not premasked:
+            g = mask_grad(g, y if relu else None, drop_p, seed)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(g, weight, trans_b=False).reshape(shape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(g, x2, trans_a=True, trans_b=False)          # [N_out, K_in] = g^T x
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(g)
+        if has_res and ctx.needs_input_grad[6]:
+            dres = g.reshape(*shape[:-1], weight.shape[0]) if not (relu or drop_p > 0.0) else None
+            if dres is None:
+                raise _lib.QTError('residual with relu/dropout epilogue is not differentiable here')
+        return dx, dw, db, None, None, None, dres, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False, drop_p: float = 0.0,
+           seed: int = 0, residual: Optional[Tensor] = None, grad_premasked: bool = False) -> Tensor:
+    return LinearFn.apply(x, weight, bias, relu, drop_p, seed, residual, grad_premasked)
+
+
+# --------------------------------------------------------------------------- #
+# attention core
+# --------------------------------------------------------------------------- #
+class AttnSpec:
+    """Geometry of one attention call (see include/qatiger.h qt_attn_fwd).
+
+    q lives in columns [q_col, q_col+E) of `qbuf`; k / v in columns [k_col, ..)
+    and [v_col, ..) of `kvbuf` (which may be `qbuf` itself for packed QKV)."""
+
+    def __init__(self, n_items, n_kv, kv_shift, H, Lq, Lk, E, q_col, k_col, v_col,
+                 q_is=None, q_rs=1, o_is=None, o_rs=1, o_rows=None):
+        self.n_items, self.n_kv, self.kv_shift, self.H = n_items, n_kv, kv_shift, H
+        self.Lq, self.Lk, self.E = Lq, Lk, E
+        self.q_col, self.k_col, self.v_col = q_col, k_col, v_col
+        self.q_is = Lq if q_is is None else q_is
+        self.q_rs = q_rs
+        self.o_is = self.q_is if o_is is None else o_is
+        self.o_rs = q_rs if o_is is None else o_rs
+        self.o_rows = n_items * Lq if o_rows is None else o_rows
+        self.dh = E // H
+        self.scale = 1.0 / math.sqrt(self.dh)
+
+
+def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int) -> Tensor:
+    _dev(qbuf, kvbuf)
+    o = torch.empty((s.o_rows, s.E), device=qbuf.device, dtype=torch.float32)
+    f4 = 4
+    rc = _lib.load().qt_attn_fwd(
+        _stream(), C.c_void_p(qbuf.data_ptr() + s.q_col * f4), _ld(qbuf), s.q_is, s.q_rs,
+        C.c_void_p(kvbuf.data_ptr() + s.k_col * f4), _ld(kvbuf),
+        C.c_void_p(kvbuf.data_ptr() + s.v_col * f4), _ld(kvbuf), s.Lk,
+        _ptr(o), s.E, s.o_is, s.o_rs,
+        s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed))
+    _lib.check(rc, 'qt_attn_fwd')
+    return o
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d_h)) -> dropout -> v, reading q/k/v in place from the
+    projection outputs.  `kvbuf is None` means packed QKV in `qbuf`."""
+
+    @staticmethod
+    def forward(ctx, qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float, seed: int):
+        qb = as2d(qbuf)
+        kb = qb if kvbuf is None else as2d(kvbuf)
+        o = _attn_fwd(qb, kb, spec, drop_p, seed)
+        ctx.save_for_backward(qb, kb if kvbuf is not None else None)
+        ctx.cfg = (spec, drop_p, seed, qbuf.shape, None if kvbuf is None else kvbuf.shape)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o: Tensor):
+        qb, kb_saved = ctx.saved_tensors
+        s, drop_p, seed, qshape, kvshape = ctx.cfg
+        packed = kb_saved is None
+        kb = qb if packed else kb_saved
+        d_o = as2d(d_o.contiguous())
+        # gradients are written in the same packed layout as the inputs.  Columns
+        # that hold no q/k/v of this call (none on this path) would stay zero.
+        dqb = torch.zeros_like(qb) if (not packed and qb.shape[1] != s.E) else torch.empty_like(qb, memory_format=torch.contiguous_format)
+        dkb = dqb if packed else torch.empty_like(kb, memory_format=torch.contiguous_format)
+        f4 = 4
+        rc = _lib.load().qt_attn_bwd(
+            _stream(), C.c_void_p(qb.data_ptr() + s.q_col * f4), _ld(qb), s.q_is, s.q_rs,
+            C.c_void_p(kb.data_ptr() + s.k_col * f4), _ld(kb),
+            C.c_void_p(kb.data_ptr() + s.v_col * f4), _ld(kb), s.Lk,
+            _ptr(d_o), _ld(d_o), s.o_is, s.o_rs,
+            C.c_void_p(dqb.data_ptr() + s.q_col * f4), _ld(dqb), s.q_is, s.q_rs,
+            C.c_void_p(dkb.data_ptr() + s.k_col * f4), _ld(dkb),
+            C.c_void_p(dkb.data_ptr() + s.v_col * f4), _ld(dkb),
+            s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed))
+        _lib.check(rc, 'qt_attn_bwd')
+        return dqb.reshape(qshape), (None if packed else dkb.reshape(kvshape)), None, None, None
+
+
+def attention(qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float = 0.0, seed: int = 0) -> Tensor:
+    return AttentionFn.apply(qbuf, kvbuf, spec, drop_p, seed)
+
+
+# --------------------------------------------------------------------------- #
+# y = LayerNorm(sum_i s_i * dropout_i(x_i))
+# --------------------------------------------------------------------------- #
+def _host_arrays(n, ptrs, lds, scales, drops, sds):
+    P = (C.c_void_p * n)(*ptrs)
+    L = (C.c_long * n)(*lds)
+    S = (C.c_float * n)(*scales)
+    Dr = (C.c_int * n)(*drops)
+    Sd = (C.c_ulonglong * n)(*sds)
+    return P, L, S, Dr, Sd
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gamma: Tensor, beta: Tensor, relu_out: bool, drop_p: float, scales, drops, sds, *xs: Tensor):
+        n = len(xs)
+        x2 = [as2d(x) for x in xs]
+        _dev(gamma, beta, *x2)
+        rows, D = x2[0].shape
+        for x in x2:
+            assert x.shape == (rows, D)
+        y = torch.empty((rows, D), device=x2[0].device, dtype=torch.float32)
+        xhat = torch.empty_like(y)
+        rstd = torch.empty((rows,), device=y.device, dtype=torch.float32)
+        P, L, S, Dr, Sd = _host_arrays(n, [x.data_ptr() for x in x2], [_ld(x) for x in x2], scales, [int(d) for d in drops], sds)
+        rc = _lib.load().qt_add_ln_fwd(_stream(), rows, D, n, P, L, S, Dr, Sd, float(drop_p), _ptr(gamma), _ptr(beta),
+                                       LN_EPS, _ptr(y), D, int(relu_out), _ptr(xhat), _ptr(rstd))
+        _lib.check(rc, 'qt_add_ln_fwd')
+        ctx.save_for_backward(gamma, xhat, rstd, y if relu_out else None)
+        ctx.cfg = (relu_out, drop_p, tuple(scales), tuple(drops), tuple(sds), [x.shape for x in xs])
+        return y.reshape(xs[0].shape)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        gamma, xhat, rstd, y = ctx.saved_tensors
+        relu_out, drop_p, scales, drops, sds, shapes = ctx.cfg
+        n = len(shapes)
+        g = as2d(dy)
+        if relu_out:
+            g = mask_grad(g, y, 0.0, 0)
+        rows, D = xhat.shape
+        dxs = [torch.empty((rows, D), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[7 + i] else None
+               for i in range(n)]
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        P = (C.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dxs])
+        L = (C.c_long * n)(*[D] * n)
+        Acc = (C.c_int * n)(*[0] * n)
+        S = (C.c_float * n)(*scales)
+        Dr = (C.c_int * n)(*[int(d) for d in drops])
+        Sd = (C.c_ulonglong * n)(*sds)
+        rc = _lib.load().qt_add_ln_bwd(_stream(), rows, D, n, _ptr(g), _ld(g), _ptr(xhat), _ptr(rstd), _ptr(gamma),
+                                       S, Dr, Sd, float(drop_p), P, L, Acc, _ptr(dgamma), _ptr(dbeta))
+        _lib.check(rc, 'qt_add_ln_bwd')
+        outs = [d.reshape(shp) if d is not None else None for d, shp in zip(dxs, shapes)]
+        return (dgamma, dbeta, None, None, None, None, None, *outs)
+
+
+def add_layer_norm(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, scales: Optional[Sequence[float]] = None,
+                   drops: Optional[Sequence[bool]] = None, drop_p: float = 0.0, relu_out: bool = False) -> Tensor:
+    n = len(xs)
+    scales = [1.0] * n if scales is None else list(scales)
+    drops = [False] * n if drops is None else list(drops)
+    sds = [seeds.next() if (d and drop_p > 0.0) else 0 for d in drops]
+    return AddLayerNormFn.apply(gamma, beta, relu_out, drop_p, scales, drops, sds, *xs)
+
+
+# --------------------------------------------------------------------------- #
+# Gaussian-expert pieces (TempMoE)
+# --------------------------------------------------------------------------- #
+class MoECoefFn(torch.autograd.Function):
+    """(router_logits [B,K], gauss_raw [B,2K]) -> coef [B,T,K], csum [B,K]
+    plus non-differentiable diagnostics (topk_inds, topk_probs, gauss)."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, raw: Tensor, T: int, K: int, k: int):
+        logits, raw = logits.contiguous(), raw.contiguous()
+        _dev(logits, raw)
+        B = logits.shape[0]
+        dev = logits.device
+        probs = torch.empty((B, K), device=dev)
+        ti = torch.empty((B, k), device=dev, dtype=torch.int64)
+        tp = torch.empty((B, k), device=dev)
+        gauss = torch.empty((B, k, T), device=dev)
+        coef = torch.empty((B, T, K), device=dev)
+        csum = torch.empty((B, K), device=dev)
+        lib = _lib.load()
+        _lib.check(lib.qt_moe_router_fwd(_stream(), _ptr(logits), _ptr(raw), B, T, K, k, _ptr(probs), _ptr(ti), _ptr(tp),
+                                         _ptr(gauss)), 'qt_moe_router_fwd')
+        _lib.check(lib.qt_moe_coef_fwd(_stream(), _ptr(ti), _ptr(tp), _ptr(gauss), B, T, K, k, _ptr(coef), _ptr(csum)),
+                   'qt_moe_coef_fwd')
+        ctx.save_for_backward(ti, tp, gauss, probs, raw)
+        ctx.dims = (B, T, K, k)
+        ctx.mark_non_differentiable(ti, tp, gauss)
+        return coef, csum, ti, tp, gauss
+
+    @staticmethod
+    def backward(ctx, dcoef, dcsum, _a, _b, _c):
+        ti, tp, gauss, probs, raw = ctx.saved_tensors
+        B, T, K, k = ctx.dims
+        if dcoef is None:
+            dcoef = torch.zeros((B, T, K), device=raw.device)
+        dcoef = dcoef.contiguous()
+        dcsum = None if dcsum is None else dcsum.contiguous()
+        dlogits = torch.empty((B, K), device=raw.device)
+        draw = torch.empty((B, 2 * K), device=raw.device)
+        rc = _lib.load().qt_moe_router_bwd(_stream(), _ptr(dcoef), _ptr(ti), _ptr(tp), _ptr(gauss), _ptr(probs), _ptr(raw),
+                                           _ptr(dcsum), B, T, K, k, _ptr(dlogits), _ptr(draw))
+        _lib.check(rc, 'qt_moe_router_bwd')
+        return dlogits, draw, None, None, None
+
+
+class MoEReduceFn(torch.autograd.Function):
+    """R[s*B+b, e, :] = Σ_t coef[b,t,e] · H[(s*B+b)*T+t, e, :].  The returned dH
+    already carries the ReLU mask of H (H is a ReLU output)."""
+
+    @staticmethod
+    def forward(ctx, H: Tensor, coef: Tensor, S: int, K: int):
+        H = as2d(H)
+        coef = coef.contiguous()
+        _dev(H, coef)
+        B, T, _ = coef.shape
+        Dh = H.shape[1] // K
+        assert H.shape[0] == S * B * T and H.is_contiguous()
+        R = torch.empty((S * B, K * Dh), device=H.device)
+        _lib.check(_lib.load().qt_moe_treduce_fwd(_stream(), _ptr(H), _ptr(coef), S, B, T, K, Dh, _ptr(R)), 'qt_moe_treduce_fwd')
+        ctx.save_for_backward(H, coef)
+        ctx.dims = (S, B, T, K, Dh)
+        return R
+
+    @staticmethod
+    def backward(ctx, dR: Tensor):
+        H, coef = ctx.saved_tensors
+        S, B, T, K, Dh = ctx.dims
+        dR = dR.contiguous()
+        dH = torch.empty_like(H)
+        dcoef = torch.empty_like(coef)
+        rc = _lib.load().qt_moe_treduce_bwd(_stream(), _ptr(H), _ptr(coef), _ptr(dR), S, B, T, K, Dh, _ptr(dH), _ptr(dcoef))
+        _lib.check(rc, 'qt_moe_treduce_bwd')
+        return dH, dcoef, None, None
+
+
+# --------------------------------------------------------------------------- #
+# loss
+# --------------------------------------------------------------------------- #
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, label: Tensor):
+        logits = as2d(logits)
+        _dev(logits)
+        label = label.contiguous()
+        assert label.dtype == torch.int64 and label.is_cuda
+        B, A = logits.shape
+        rows = torch.empty((B,), device=logits.device)
+        mean = torch.empty((), device=logits.device)
+        dlog = torch.empty((B, A), device=logits.device)
+        rc = _lib.load().qt_xent_fwd_bwd(_stream(), _ptr(logits), _ld(logits), _ptr(label), B, A, _ptr(rows), _ptr(mean),
+                                         _ptr(dlog), A)
+        _lib.check(rc, 'qt_xent_fwd_bwd')
+        ctx.save_for_backward(dlog)
+        return mean
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None      # scalar chain-rule factor (1.0 for loss.backward())
+
+
+def cross_entropy(logits: Tensor, label: Tensor) -> Tensor:
+    return CrossEntropyFn.apply(logits, label)
+
+
+def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
+               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    """In-place torch.optim.Adam update on flat fp32 buffers."""
+    _dev(param, grad, exp_avg, exp_avg_sq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.is_contiguous() and t.numel() == param.numel()
+    rc = _lib.load().qt_adam_step(_stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step),
+                                  float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale))
+    _lib.check(rc, 'qt_adam_step')

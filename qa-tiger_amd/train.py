@@ -1,0 +1,196 @@
+"""The `train()` step of the reference (src/trainutils.py:269-287) re-built for
+one-process-per-GPU data parallelism on MI355X:
+
+    zero_grad -> model(batch) -> CrossEntropyLoss -> backward -> [grad all-reduce] -> Adam.step
+
+* `CrossEntropyLoss`  — nn.CrossEntropyLoss(mean) on the HIP loss kernel (train.py:41).
+* `FlatParams`        — all trainable parameters live in ONE flat fp32 buffer (each
+                        parameter a 16-byte-aligned view), with a matching flat gradient buffer.
+* `GradSync`          — replaces DDP's bucketed gradient all-reduce (trainutils.py:103-106):
+                        gradients are copied into the flat buffer as autograd finishes them and
+                        each contiguous bucket is all-reduced asynchronously (RCCL over xGMI when
+                        the backend is "nccl") while the rest of backward still runs.
+* `FusedAdam`         — torch.optim.Adam(lr, betas, eps, weight_decay=0) (trainutils.py:141-144)
+                        as one kernel over the flat buffers; the 1/world averaging is folded in.
+* `DataParallelStep`  — the step above, end to end.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+
+_ALIGN = 4          # elements: every parameter view starts on a 16-byte boundary
+
+
+class CrossEntropyLoss(nn.Module):
+    """Drop-in for the `criterion` of reference train.py:41 (mean reduction, int64 targets)."""
+
+    def forward(self, logits: Tensor, target: Tensor) -> Tensor:
+        return ops.cross_entropy(logits, target)
+
+
+class FlatParams:
+    def __init__(self, params: Iterable[nn.Parameter]):
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError('all parameters must share one device and dtype')
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.flat = torch.zeros(self.total, device=dev, dtype=dt)
+        self.grad = torch.zeros(self.total, device=dev, dtype=dt)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view                     # the module now computes from the flat buffer
+        self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+
+    def numel(self) -> int:
+        return sum(p.numel() for p in self.params)
+
+
+class GradSync:
+    """Copy finished gradients into `flat.grad` and all-reduce them bucket by bucket.
+
+    Buckets are contiguous slices of the flat buffer, filled from the END of the
+    parameter list (autograd finishes the last-registered parameters first), so
+    the first bucket is on the wire while most of backward is still to run.
+    """
+
+    def __init__(self, flat: FlatParams, process_group=None, bucket_bytes: int = 32 << 20):
+        self.flat = flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        n = len(flat.params)
+        self.bucket_of = [0] * n
+        self.buckets: List[List[int]] = []        # [lo, hi, n_params]
+        cur_hi, cur_lo, cur_n, b = flat.total, flat.total, 0, 0
+        elem = flat.flat.element_size()
+        for i in range(n - 1, -1, -1):
+            cur_lo = flat.offsets[i]
+            cur_n += 1
+            self.bucket_of[i] = b
+            if (cur_hi - cur_lo) * elem >= bucket_bytes or i == 0:
+                self.buckets.append([cur_lo, cur_hi, cur_n])
+                cur_hi, cur_n, b = cur_lo, 0, b + 1
+        self._pending = [0] * len(self.buckets)
+        self._seen = [False] * n
+        self._works = []
+        self._fired = [False] * len(self.buckets)
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.begin()
+
+    def _make_hook(self, i: int):
+        def hook(p: Tensor):
+            gv = self.flat.grad_views[i]
+            if p.grad is not gv:
+                gv.copy_(p.grad)
+                p.grad = gv                        # later accumulations (shared weights) add in place
+            if not self._seen[i]:
+                self._seen[i] = True
+                b = self.bucket_of[i]
+                self._pending[b] -= 1
+                if self._pending[b] == 0:
+                    self._fire(b)
+        return hook
+
+    def _fire(self, b: int):
+        self._fired[b] = True
+        if self.world > 1:
+            lo, hi, _ = self.buckets[b]
+            self._works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def begin(self):
+        """Call before backward: forget last step's gradients (grad=None => autograd
+        hands over fresh tensors, no memset of the flat buffer needed)."""
+        for p in self.flat.params:
+            p.grad = None
+        self._pending = [bk[2] for bk in self.buckets]
+        self._seen = [False] * len(self.flat.params)
+        self._fired = [False] * len(self.buckets)
+        self._works = []
+
+    def finish(self):
+        """Call after backward: parameters that got no gradient this step count as
+        zero; flush unfinished buckets; wait for the collectives."""
+        for i, seen in enumerate(self._seen):
+            if not seen:
+                self.flat.grad_views[i].zero_()
+        for b, fired in enumerate(self._fired):
+            if not fired:
+                self._fire(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
+class FusedAdam:
+    def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-8):
+        self.flat, self.lr, self.betas, self.eps = flat, lr, tuple(betas), eps
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.step_count = 0
+
+    def step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
+                       self.lr, self.betas, self.eps, grad_scale)
+
+    def state_dict(self) -> dict:
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr,
+                    betas=self.betas, eps=self.eps)
+
+
+class DataParallelStep:
+    """One rank of the data-parallel train step (weights replicated, batch sharded
+    along dim 0 exactly like `DistributedSampler` + `batch_size // world`,
+    reference trainutils.py:191-194)."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-8,
+                 process_group=None, bucket_bytes: int = 32 << 20):
+        self.model = model
+        self.flat = FlatParams(model.parameters())
+        self.sync = GradSync(self.flat, process_group, bucket_bytes)
+        self.optim = FusedAdam(self.flat, lr, betas, eps)
+        self.criterion = CrossEntropyLoss()
+
+    def forward_backward(self, batch: Dict[str, Tensor]) -> Tensor:
+        self.sync.begin()
+        out = self.model(batch)
+        loss = self.criterion(out['out'], batch['label'])
+        loss.backward()
+        self.sync.finish()
+        return loss.detach()
+
+    def step(self, batch: Dict[str, Tensor]) -> Tensor:
+        loss = self.forward_backward(batch)
+        self.optim.step(grad_scale=1.0 / self.sync.world)
+        return loss
+
+
+def shard_batch(batch: Dict[str, Tensor], rank: int, world: int) -> Dict[str, Tensor]:
+    """Contiguous split of the global batch along dim 0 (B_local = B / world)."""
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, Tensor) and v.dim() >= 1:
+            B = v.shape[0]
+            if B % world:
+                raise ValueError(f'global batch {B} is not divisible by world size {world}')
+            per = B // world
+            out[k] = v[rank * per:(rank + 1) * per]
+        else:
+            out[k] = v
+    return out

@@ -1,0 +1,221 @@
+"""End-to-end parity of the HIP path (through the nn.Module surface and the
+C ABI) against (a) golden vectors produced by the reference itself and (b) the
+CPU oracle on the same seeded inputs.  GPU box only.
+
+Gate (BASELINE.json north_star / SURVEY.md §8d): max|Δlogit| / max|logit| <= 1e-3
+and identical arg-max answers, eval mode, identical per-device batch composition.
+The fp32 kernels are expected to land near 1e-5; the asserted bound is 1e-4 so a
+precision regression is caught long before the gate."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_cfg, rel_err, GOLDEN_CONFIGS
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+GATE = 1e-3
+EXPECT = 1e-4
+
+
+def build(qt, synth, cfg, seed):
+    model = qt.QA_TIGER(**cfg.model_kwargs())
+    model.load_state_dict(synth.make_state_dict(cfg, seed), strict=True)
+    return model.to(DEV).eval()
+
+
+def to_dev(inp):
+    return {k: v.to(DEV) for k, v in inp.items()}
+
+
+def run(qt, synth, name):
+    cfg, seed = golden_cfg(synth, name)
+    model = build(qt, synth, cfg, seed)
+    inp = to_dev(synth.make_inputs(cfg, seed))
+    out = model(inp)['out']
+    loss = qt.CrossEntropyLoss()(out, inp['label'])
+    loss.backward()
+    return cfg, model, inp, out, loss
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CONFIGS))
+def test_logits_argmax_loss_vs_reference_golden(qt, synth, name):
+    g = load_golden(name)
+    cfg, model, inp, out, loss = run(qt, synth, name)
+    e = rel_err(out.detach().cpu().numpy(), g['logits'])
+    assert e < EXPECT < GATE, e
+    assert (out.argmax(-1).cpu().numpy() == g['logits'].argmax(-1)).all()
+    assert float(loss) == pytest.approx(float(g['loss']), rel=1e-5)
+    for agg in ('at_aggregator', 'vt_aggregator'):
+        last = getattr(model, agg).last
+        if f'tap/{agg}.topk_inds' in g:
+            assert (last['topk_inds'].cpu().numpy() == g[f'tap/{agg}.topk_inds']).all(), \
+                f'top-k order differs (min router gap {float(g[f"router_gap/{agg}"]):.2e})'
+            assert rel_err(last['gauss'].cpu().numpy(), g[f'tap/{agg}.gauss']) < 1e-4
+            assert rel_err(last['topk_probs'].cpu().numpy(), g[f'tap/{agg}.topk_probs']) < 1e-4
+            assert rel_err(last['temp_w'].cpu().numpy(), g[f'tap/{agg}.temp_w']) < 1e-4
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CONFIGS))
+def test_gradients_vs_reference_golden(qt, synth, name):
+    g = load_golden(name)
+    cfg, model, inp, out, loss = run(qt, synth, name)
+    n = 0
+    for pname, p in model.named_parameters():
+        assert p.grad is not None, f'{pname} got no gradient (DDP find_unused_parameters=False contract)'
+        gr = p.grad.detach().cpu().numpy()
+        if f'grad/{pname}' in g:
+            ref = g[f'grad/{pname}']
+            assert np.abs(gr - ref).max() / max(np.abs(ref).max(), 1e-8) < 1e-3, pname
+        else:
+            assert float(np.sqrt((gr.astype(np.float64) ** 2).sum())) == pytest.approx(float(g[f'gradnorm/{pname}']), rel=1e-3, abs=1e-9), pname
+            flat = gr.reshape(-1)
+            sl = flat[:: max(1, flat.size // 256)][:256]
+            ref = g[f'gradslice/{pname}']
+            assert np.abs(sl - ref).max() / max(np.abs(ref).max(), 1e-8) < 2e-3, pname
+        n += 1
+    assert n == len(synth.param_shapes(cfg))
+
+
+def test_module_outputs_vs_reference_golden(qt, synth):
+    g = load_golden('toy')
+    cfg, seed = golden_cfg(synth, 'toy')
+    model = build(qt, synth, cfg, seed)
+    inp = to_dev(synth.make_inputs(cfg, seed))
+    with torch.no_grad():
+        audio = model.audio_proj(inp['audio']); video = model.video_proj(inp['video'])
+        words = model.words_proj(inp['words_feat']); quest = model.quest_proj(inp['quest_feat'])
+        patch = model.patch_proj(inp['patch'])
+        audio, video = model.crs_attn(audio, video, words)
+        assert rel_err(audio.cpu().numpy(), g['tap/crs_attn.audio']) < EXPECT
+        assert rel_err(video.cpu().numpy(), g['tap/crs_attn.video']) < EXPECT
+        pa, pv = model.patch_selecter(patch, audio, video)
+        assert rel_err(pa.cpu().numpy(), g['tap/patch_selecter.a']) < EXPECT
+        assert rel_err(pv.cpu().numpy(), g['tap/patch_selecter.v']) < EXPECT
+        a_g = model.at_aggregator(quest, audio)
+        assert rel_err(a_g.cpu().numpy(), g['tap/at_aggregator.out']) < EXPECT
+        ap, vp = model.vt_aggregator(quest, video, [pa, pv])
+        assert rel_err(ap.cpu().numpy(), g['tap/vt_aggregator.a_out']) < EXPECT
+        assert rel_err(vp.cpu().numpy(), g['tap/vt_aggregator.v_out']) < EXPECT
+        f1 = model.quest_grounding(quest, [ap, vp])
+        assert rel_err(f1.cpu().numpy(), g['tap/quest_grounding.1']) < EXPECT
+        f2 = model.quest_grounding(quest, [f1.unsqueeze(1), a_g])
+        assert rel_err(f2.cpu().numpy(), g['tap/quest_grounding.2']) < EXPECT
+
+
+def _oracle_vs_hip(qt, synth, oracle, cfg, seed, with_grads):
+    P = synth.make_state_dict(cfg, seed)
+    inp = synth.make_inputs(cfg, seed)
+    model = qt.QA_TIGER(**cfg.model_kwargs())
+    model.load_state_dict(P, strict=True)
+    model = model.to(DEV).eval()
+    dinp = to_dev(inp)
+    taps = {}
+    if with_grads:
+        out = model(dinp)['out']
+        qt.CrossEntropyLoss()(out, dinp['label']).backward()
+        loss_r, logits_r, grads_r = oracle.forward_backward(P, inp, cfg.K, cfg.k, taps=taps)
+    else:
+        with torch.no_grad():
+            out = model(dinp)['out']
+            logits_r = oracle.qa_tiger_forward(P, inp, cfg.K, cfg.k, taps=taps)
+        grads_r = None
+    gaps = [oracle.min_router_gap(taps[f'{a}.router_logits']) for a in ('at_aggregator', 'vt_aggregator')]
+    e = rel_err(out.detach().cpu().numpy(), logits_r.numpy())
+    same = bool((out.argmax(-1).cpu() == logits_r.argmax(-1)).all())
+    for a in ('at_aggregator', 'vt_aggregator'):
+        assert torch.equal(getattr(model, a).last['topk_inds'].cpu(), taps[f'{a}.topk_inds']), f'top-k order flip, gaps {gaps}'
+    assert e < EXPECT < GATE, (e, gaps)
+    assert same, gaps
+    if grads_r is not None:
+        for n, p in model.named_parameters():
+            ref = grads_r[n]
+            assert float((p.grad.cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-8)) < 2e-3, n
+    return e, gaps
+
+
+def test_config2_b32_fwd_bwd_vs_oracle(qt, synth, oracle):
+    """ViT-L/14 shape (T=60, D=768, K=8) at B=32: logits, arg-max, top-k order and every gradient."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 32})
+    _oracle_vs_hip(qt, synth, oracle, cfg, 713, with_grads=True)
+
+
+def test_config2_full_b256_forward_vs_oracle(qt, synth, oracle):
+    """BASELINE config 2 at its full size: B=256, T=60, D=768, K=8 (CPU oracle forward ~10-20 s)."""
+    e, gaps = _oracle_vs_hip(qt, synth, oracle, synth.CONFIG_2, 713, with_grads=False)
+    print(f'B=256 rel logit err {e:.2e}, min router gaps {gaps}')
+
+
+def test_full_size_invariances(qt, synth):
+    """Size-independent properties at B=256: the path has no positional term on patch
+    tokens or words and no masks, so permuting them must not
+    change the logits; and eval mode is deterministic."""
+    cfg = synth.CONFIG_2
+    model = build(qt, synth, cfg, 713)
+    inp = qt.synth.fast_device_inputs(cfg, DEV, seed=5)
+    with torch.no_grad():
+        base = model(inp)['out']
+        again = model(inp)['out']
+        assert torch.equal(base, again)
+        pp = torch.randperm(cfg.P, device=DEV)
+        out_p = model({**inp, 'patch': inp['patch'][:, :, pp]})['out']
+        wp = torch.randperm(cfg.L, device=DEV)
+        out_w = model({**inp, 'words_feat': inp['words_feat'][:, wp]})['out']
+    scale = float(base.abs().max())
+    assert torch.isfinite(base).all()
+    assert float((out_p - base).abs().max()) / scale < 1e-4
+    assert float((out_w - base).abs().max()) / scale < 1e-4
+
+
+def test_batch_composition_dependence_matches_reference(qt, synth):
+    """Quirk Q1 must be reproduced: the same samples in a smaller batch give different logits."""
+    cfg, seed = golden_cfg(synth, 'toy')
+    model = build(qt, synth, cfg, seed)
+    inp = to_dev(synth.make_inputs(cfg, seed))
+    with torch.no_grad():
+        full = model(inp)['out']
+        part = model({k: v[:3] for k, v in inp.items()})['out']
+    assert float((full[:3] - part).abs().max()) > 1e-3
+
+
+def test_train_step_matches_oracle_adam_in_eval_mode(qt, synth, oracle):
+    """zero_grad -> forward -> CE -> backward -> Adam (reference trainutils.py:273-287), dropout off."""
+    cfg, seed = golden_cfg(synth, 'toy_kk')
+    P = synth.make_state_dict(cfg, seed)
+    inp = synth.make_inputs(cfg, seed)
+    model = build(qt, synth, cfg, seed)            # eval(): dropout off, same arithmetic as the oracle
+    eng = qt.DataParallelStep(model, lr=1e-4, betas=(0.95, 0.999))
+    ref = {n: t.clone() for n, t in P.items()}
+    m = {n: torch.zeros_like(t) for n, t in P.items()}
+    v = {n: torch.zeros_like(t) for n, t in P.items()}
+    for step in range(1, 4):
+        loss = eng.step(to_dev(inp))
+        loss_r, _, grads = oracle.forward_backward(ref, inp, cfg.K, cfg.k)
+        oracle.adam_step(ref, grads, m, v, step)
+        assert float(loss) == pytest.approx(float(loss_r), rel=2e-5)
+    for n, p in model.named_parameters():
+        # after 3 steps each weight moved by ~3e-4; compare the UPDATE, not the weight
+        upd, upd_r = p.detach().cpu() - P[n], ref[n] - P[n]
+        assert float((upd - upd_r).abs().max()) < 2e-5, n
+
+
+def test_train_mode_dropout_and_loss_decreases(qt, synth):
+    cfg = synth.CONFIG_TOY_KK
+    torch.manual_seed(0)
+    qt.ops.seeds.reset()
+    model = qt.QA_TIGER(**cfg.model_kwargs()).to(DEV).train()
+    inp = to_dev(synth.make_inputs(cfg, 3))
+    with torch.no_grad():
+        a, b = model(inp)['out'], model(inp)['out']
+    assert not torch.equal(a, b)                   # dropout active, fresh masks per call
+    eng = qt.DataParallelStep(model, lr=1e-3)
+    losses = [float(eng.step(inp)) for _ in range(30)]
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.3
+
+
+def test_cpu_tensors_fail_loudly(qt, synth):
+    cfg = synth.CONFIG_TOY
+    model = qt.QA_TIGER(**cfg.model_kwargs())
+    with pytest.raises(qt.QTError, match='no CPU fallback'):
+        model(synth.make_inputs(cfg))
