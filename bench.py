@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the QA-TIGER fusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = the reference's `train()` body (src/trainutils.py:273-287) on one batch
+of synthetic features: zero_grad -> QA_TIGER.forward (train mode, dropout on) ->
+CrossEntropyLoss -> backward -> [gradient all-reduce over RCCL] -> Adam.step.
+Workload = BASELINE.json configs[1]: B=256 per GPU, T=60, D=768, K=8 experts
+(k=8, P=14 patches, L=77 words, Da=128, Dp=1024), fp32, inputs resident in HBM.
+Weak scaling: every rank processes its own B=256 batch; the only exchange is the
+gradient all-reduce.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel family (projection GEMMs, MFMA-bound)
+  attention     the attention-core kernels against the HBM roofline
+  cpu_baseline  the CPU oracle timed on this host's cores (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# reference-executed GEMM FLOPs per sample at B=256,T=60,D=768,K=8 (torch FlopCounterMode)
+GFLOP_FWD, GFLOP_FWD_BWD = 12.048, 34.647
+ATTN_MB_FWD = 21.6                       # attention-core algorithmic bytes per sample, fwd
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--strong', action='store_true', help='shard a GLOBAL batch of --batch over the ranks instead')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=16, help='batch of the bounded CPU-baseline sample')
+    ap.add_argument('--profile-steps', type=int, default=2, help='extra instrumented steps for the roofline (after the timed region)')
+    return ap.parse_args()
+
+
+def cpu_baseline(qt, sample_b: int):
+    """CPU oracle (port of the reference's execution plan) on this host: fwd+bwd, train mode."""
+    oracle = importlib.import_module('oracle.qatiger_oracle')
+    synth = qt.synth
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': sample_b})
+    cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0)))
+    torch.set_num_threads(cores)
+    P = synth.make_state_dict(cfg, 713)
+    g = torch.Generator().manual_seed(713)
+    inp = dict(audio=torch.randn(cfg.B, cfg.T, cfg.Da, generator=g), video=torch.randn(cfg.B, cfg.T, cfg.Dv, generator=g),
+               patch=torch.randn(cfg.B, cfg.T, cfg.P, cfg.Dp, generator=g), quest_feat=torch.randn(cfg.B, cfg.Dv, generator=g),
+               words_feat=torch.randn(cfg.B, cfg.L, cfg.Dv, generator=g), label=torch.randint(0, cfg.A, (cfg.B,), generator=g))
+    small = {k: v[:2] for k, v in inp.items()}
+    oracle.forward_backward(P, small, cfg.K, cfg.k, train=True)          # thread-pool / allocator warm-up
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oracle.forward_backward(P, inp, cfg.K, cfg.k, train=True)
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return dict(value=round(cfg.B / t, 3), unit='QA-pairs/s', cores=cores, kind='port',
+                sample=f'oracle/qatiger_oracle.py fwd+bwd+CE, train mode, B={cfg.B} (T=60,D=768,K=8), best of 2, {t:.2f} s/iter, '
+                       f'torch {torch.__version__} CPU fp32')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)     # "nccl" is RCCL on ROCm
+    qt = importlib.import_module('qa-tiger_amd')
+    synth, ops = qt.synth, qt.ops
+
+    per_gpu = args.batch // world if args.strong else args.batch
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': per_gpu})
+    torch.manual_seed(713)                                    # reference seed (configs/qa-tiger/vitl14.py:4)
+    model = qt.QA_TIGER(**cfg.model_kwargs())                 # reference initialisers, identical on every rank
+    model = model.to(dev).train()
+    eng = qt.DataParallelStep(model, lr=1e-4, betas=(0.95, 0.999))
+    batch = synth.fast_device_inputs(cfg, dev, seed=713 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    ms_step = dt / args.steps * 1e3
+    value = per_gpu * world * args.steps / dt
+
+    # ---- forward-only (eval, no_grad): the north-star's ">= 10k QA-pairs/s forward" figure
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            model(batch)
+        sync()
+        t1 = time.perf_counter()
+        n_fwd = max(3, args.steps)
+        for _ in range(n_fwd):
+            model(batch)
+        sync()
+        fwd_dt = time.perf_counter() - t1
+    model.train()
+    fwd_value = per_gpu * world * n_fwd / fwd_dt
+
+    # ---- instrumented steps: HIP events around every kernel launch of the two dominant families
+    roofline = attention = None
+    if args.profile_steps > 0:
+        ops.timer = ops.KernelTimer()
+        for _ in range(args.profile_steps):
+            eng.step(batch)
+        summ = ops.timer.summary()
+        ops.timer = None
+        n = args.profile_steps
+        scale = cfg.B / 256.0                                 # algorithmic figures are per sample
+        gm = summ['gemm']
+        gemm_ms = gm['ms'] / n
+        algo_tf = GFLOP_FWD_BWD * 1e9 * cfg.B / (gemm_ms * 1e-3) / 1e12
+        exec_tf = gm['work'] / n / (gemm_ms * 1e-3) / 1e12
+        top = sorted(gm['by_detail'].items(), key=lambda kv: -kv[1][0])[:4]
+        roofline = dict(bound='mfma', kernel='qt_gemm_f32_kernel (all projection/MLP GEMM launches of one step, fwd+bwd)',
+                        achieved=round(algo_tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(algo_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                        traffic=None,
+                        algorithmic_gflop_per_sample=GFLOP_FWD_BWD, executed_tflops=round(exec_tf, 2),
+                        executed_frac=round(exec_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                        launches_per_step=gm['launches'] // n, avg_launch_ms=round(gemm_ms / (gm['launches'] / n), 4),
+                        gemm_ms_per_step=round(gemm_ms, 3), share_of_step=round(gemm_ms / ms_step, 3),
+                        top_shapes=[dict(MNK_tAtB=list(k), ms_per_step=round(v[0] / n, 3), launches=v[2] // n,
+                                         tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 1)) for k, v in top])
+        a_ms = (summ.get('attn_fwd', {'ms': 0})['ms'] + summ.get('attn_bwd', {'ms': 0})['ms']) / n
+        a_bytes = (summ.get('attn_fwd', {'work': 0})['work'] + summ.get('attn_bwd', {'work': 0})['work']) / n
+        if a_ms > 0:
+            gbs = a_bytes / (a_ms * 1e-3) / 1e9
+            attention = dict(bound='hbm', kernel='qt_attn_fwd_kernel + qt_attn_bwd_kernel (12 + 12 launches per step)',
+                             achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                             algorithmic_mb_per_sample=round(a_bytes / cfg.B / 1e6, 2), ms_per_step=round(a_ms, 3),
+                             share_of_step=round(a_ms / ms_step, 3))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(qt, args.cpu_sample)
+
+    if rank == 0:
+        out = {
+            'metric': 'QA-pairs/sec fwd+bwd at B=256 T=60 D=768 K=8',
+            'value': round(value, 2), 'unit': 'QA-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: train step (fwd + CE + bwd + grad all-reduce + Adam, dropout on) on synthetic '
+                                   'CLIP/VGGish/ToMe-shaped features, reference initialisers',
+                       'per_gpu_batch': per_gpu, 'global_batch': per_gpu * world, 'T': cfg.T, 'D': cfg.D, 'video_dim': cfg.Dv,
+                       'audio_dim': cfg.Da, 'patch_dim': cfg.Dp, 'P': cfg.P, 'L': cfg.L, 'experts': cfg.K, 'topK': cfg.k,
+                       'parallelism': f'dp{world}'},
+            'fwd_only': {'value': round(fwd_value, 2), 'unit': 'QA-pairs/s', 'mode': 'eval, no_grad', 'target': 10000,
+                         'mfma_frac_algorithmic': round(fwd_value * GFLOP_FWD * 1e9 / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4)},
+            'loss': round(float(loss), 5),
+            'roofline': roofline, 'attention': attention, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

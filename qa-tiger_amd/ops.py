@@ -74,6 +74,40 @@ class _Seeds:
 seeds = _Seeds()
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels
+    are launched on (torch's current stream).  Used by bench.py for the roofline."""
+
+    def __init__(self):
+        self.records = []          # (family, work, detail, start_event, end_event)
+
+    def launch(self, family: str, work: float, detail, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.records.append((family, work, detail, e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, work, detail, e0, e1 in self.records:
+            d = out.setdefault(fam, dict(ms=0.0, work=0.0, launches=0, by_detail={}))
+            ms = e0.elapsed_time(e1)
+            d['ms'] += ms; d['work'] += work; d['launches'] += 1
+            bd = d['by_detail'].setdefault(detail, [0.0, 0.0, 0])
+            bd[0] += ms; bd[1] += work; bd[2] += 1
+        return out
+
+
+timer: Optional[KernelTimer] = None
+
+
+def _launch(family: str, work: float, detail, fn):
+    return fn() if timer is None else timer.launch(family, work, detail, fn)
+
+
 # --------------------------------------------------------------------------- #
 # raw kernel calls (no autograd)
 # --------------------------------------------------------------------------- #
@@ -99,12 +133,12 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     if mask_src is not None:
         mask_src = as2d(mask_src)
         assert mask_src.shape == (M, N)
-    rc = _lib.load().qt_gemm_f32(
+    rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b)), lambda: _lib.load().qt_gemm_f32(
         _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
         _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
         _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
-        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k))
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k)))
     _lib.check(rc, 'qt_gemm_f32')
     return out
 
@@ -209,12 +243,13 @@ def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int
     _dev(qbuf, kvbuf)
     o = torch.empty((s.o_rows, s.E), device=qbuf.device, dtype=torch.float32)
     f4 = 4
-    rc = _lib.load().qt_attn_fwd(
+    nbytes = 4.0 * s.E * (2 * s.n_items * s.Lq + 2 * s.n_kv * s.Lk)
+    rc = _launch('attn_fwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_fwd(
         _stream(), C.c_void_p(qbuf.data_ptr() + s.q_col * f4), _ld(qbuf), s.q_is, s.q_rs,
         C.c_void_p(kvbuf.data_ptr() + s.k_col * f4), _ld(kvbuf),
         C.c_void_p(kvbuf.data_ptr() + s.v_col * f4), _ld(kvbuf), s.Lk,
         _ptr(o), s.E, s.o_is, s.o_rs,
-        s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed))
+        s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed)))
     _lib.check(rc, 'qt_attn_fwd')
     return o
 
@@ -244,7 +279,8 @@ class AttentionFn(torch.autograd.Function):
         dqb = torch.zeros_like(qb) if (not packed and qb.shape[1] != s.E) else torch.empty_like(qb, memory_format=torch.contiguous_format)
         dkb = dqb if packed else torch.empty_like(kb, memory_format=torch.contiguous_format)
         f4 = 4
-        rc = _lib.load().qt_attn_bwd(
+        nbytes = 4.0 * s.E * (3 * s.n_items * s.Lq + 4 * s.n_kv * s.Lk)      # q, dO, dq + k, v, dk, dv
+        rc = _launch('attn_bwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_bwd(
             _stream(), C.c_void_p(qb.data_ptr() + s.q_col * f4), _ld(qb), s.q_is, s.q_rs,
             C.c_void_p(kb.data_ptr() + s.k_col * f4), _ld(kb),
             C.c_void_p(kb.data_ptr() + s.v_col * f4), _ld(kb), s.Lk,
@@ -252,7 +288,7 @@ class AttentionFn(torch.autograd.Function):
             C.c_void_p(dqb.data_ptr() + s.q_col * f4), _ld(dqb), s.q_is, s.q_rs,
             C.c_void_p(dkb.data_ptr() + s.k_col * f4), _ld(dkb),
             C.c_void_p(dkb.data_ptr() + s.v_col * f4), _ld(dkb),
-            s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed))
+            s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed)))
         _lib.check(rc, 'qt_attn_bwd')
         return dqb.reshape(qshape), (None if packed else dkb.reshape(kvshape)), None, None, None
 
