@@ -196,6 +196,380 @@ __global__ __launch_bounds__(NT) void qt_attn_bwd_kernel(AttnArgs p) {
     }
 }
 
+
+// ============================================================================
+// Matrix-core path (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate)
+// ============================================================================
+// Used when d_h is a multiple of 16 (<=128), Lk <= 128 and rows are 16-byte aligned;
+// the VALU kernels above remain the generic path for odd shapes.
+//
+// Lane roles of the 16x16x4 MFMA: c = lane&15, g = lane>>4.
+//   A operand: A[row=c][k=g]    B operand: B[k=g][col=c]    C/D reg j: [row=4g+j][col=c]
+//
+// Forward, per wave and 16-query tile:
+//   S^T tile (keys x queries) = K_tile · Q_tile^T  — "swapped" so that a lane owns ONE query
+//   column: lane (c,g) holds scores of query c for keys {16kt + 4g + j}.  The softmax row
+//   reduction is a register reduce + two shuffles (xor 16, 32).  K rows come from LDS as
+//   16-byte vectors; the 4 elements of a vector are used in 4 consecutive MFMA k-steps, the
+//   same permutation on the Q side, which a dot product does not care about.
+//   O tile = P · V: the P registers ARE the A operand (row = query c, k-step j covers keys
+//   16kt + 4g + j), V rows are dword LDS reads (row stride d_h+4 keeps the two 16-lane
+//   halves on disjoint banks).  No score ever leaves the registers.
+// Backward: phase A (wave per query tile) recomputes P, forms dP^T = V·dO^T the same way,
+//   dS = P∘(dP − Σ dP∘P), dQ = dS·K from registers, and parks P_dropped^T and dS^T in LDS
+//   [key][query]; phase B (wave per key tile) computes dV = P^T·dO and dK = dS^T·Q with the
+//   query index as the MFMA k dimension, so dK/dV need no atomics.
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+
+template <int DC, int NKT>
+__global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int wpp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DH = DC * 16, LDK = DH + 4, KR = NKT * 16, V4 = DH / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int ppb = 4 / wpp, pl = wave / wpp, wip = wave - pl * wpp;
+    const long prob = (long)blockIdx.x * ppb + pl;
+    const bool active = prob < (long)p.n_items * p.H;
+    const int n = active ? (int)(prob / p.H) : 0, hd = active ? (int)(prob - (long)n * p.H) : 0;
+    const int kvn = (n + p.kv_shift) % p.n_kv;
+    const int Lq = p.Lq, Lk = p.Lk;
+    float* Ks = lds + pl * (2 * KR * LDK);
+    float* Vs = Ks + KR * LDK;
+    for (int idx = wip * 64 + lane; idx < KR * V4; idx += wpp * 64) {
+        const int j = idx / V4, c4 = idx - j * V4;
+        float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+        if (active && j < Lk) {
+            const long row = (long)kvn * p.kv_is + j;
+            kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
+            vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+        }
+        *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk;
+        *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv;
+    }
+    __syncthreads();
+    if (!active) return;
+    for (int q0 = wip * 16; q0 < Lq; q0 += wpp * 16) {
+        const int q = q0 + c;
+        const bool qok = q < Lq;
+        float4 qf[DC];
+#pragma unroll
+        for (int ch = 0; ch < DC; ++ch) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qok) t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)q * p.q_rs) * p.ldq + hd * DH + ch * 16 + g * 4);
+            qf[ch] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+        }
+        floatx4v st[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            floatx4v acc = {0.f, 0.f, 0.f, 0.f};
+            if (kt * 16 < Lk) {
+#pragma unroll
+                for (int ch = 0; ch < DC; ++ch) {
+                    const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[ch].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[ch].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[ch].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[ch].w, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (kt * 16 + g * 4 + j >= Lk) acc[j] = -INFINITY;
+                mx = fmaxf(mx, acc[j]);
+            }
+            st[kt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float e = __expf(st[kt][j] - mx); st[kt][j] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        const unsigned long long base = (((unsigned long long)n * p.H + hd) * Lq + (qok ? q : 0)) * (unsigned long long)Lk;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pr = st[kt][j] * inv;
+                const int key = kt * 16 + g * 4 + j;
+                if (p.drop_p > 0.f && key < Lk) pr *= qt_drop_mult(p.seed, base + key, p.drop_p, p.inv_keep);
+                st[kt][j] = pr;
+            }
+        floatx4v oacc[DC];
+#pragma unroll
+        for (int dt = 0; dt < DC; ++dt) oacc[dt] = floatx4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt * 16 >= Lk) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* vrow = Vs + (kt * 16 + g * 4 + j) * LDK + c;
+#pragma unroll
+                for (int dt = 0; dt < DC; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][j], vrow[dt * 16], oacc[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qo = q0 + g * 4 + j;
+            if (qo < Lq) {
+                float* orow = p.o + ((long)n * p.o_is + (long)qo * p.o_rs) * p.ldo + hd * DH + c;
+#pragma unroll
+                for (int dt = 0; dt < DC; ++dt) orow[dt * 16] = oacc[dt][j];
+            }
+        }
+    }
+}
+
+template <int DC, int NKT>
+__global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int wpp, int nqt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DH = DC * 16, LDK = DH + 4, KR = NKT * 16, V4 = DH / 4;
+    const int LDQ = nqt * 16 + 4, QR = nqt * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int ppb = 4 / wpp, pl = wave / wpp, wip = wave - pl * wpp;
+    const long prob = (long)blockIdx.x * ppb + pl;
+    const bool active = prob < (long)p.n_kv * p.H;
+    const int kvn = active ? (int)(prob / p.H) : 0, hd = active ? (int)(prob - (long)kvn * p.H) : 0;
+    const int Lq = p.Lq, Lk = p.Lk;
+    const int regA = (2 * KR > 2 * QR ? 2 * KR : 2 * QR) * LDK;        // K|V during phase A, Q|dO during phase B
+    float* base_l = lds + pl * (regA + 2 * KR * LDQ);
+    float* Ks = base_l;
+    float* Vs = Ks + KR * LDK;
+    float* Qs = base_l;                                                 // overlay (after the phase-A barrier)
+    float* Gs = Qs + QR * LDK;
+    float* PT = base_l + regA;                                          // [key][query] dropped P
+    float* ST = PT + KR * LDQ;                                          // [key][query] dS
+    int first = (kvn - p.kv_shift) % p.n_kv;
+    if (first < 0) first += p.n_kv;
+    const int reps = p.n_items / p.n_kv;                                // uniform trip count (host guarantees divisibility)
+    for (int rep = 0; rep < reps; ++rep) {
+        const int n = first + rep * p.n_kv;
+        __syncthreads();                                                // previous phase B done with Q|dO and PT|ST
+        for (int idx = wip * 64 + lane; idx < KR * V4; idx += wpp * 64) {
+            const int j = idx / V4, c4 = idx - j * V4;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (active && j < Lk) {
+                const long row = (long)kvn * p.kv_is + j;
+                kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk;
+            *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv;
+        }
+        __syncthreads();
+        // ---------------- phase A: one wave per 16-query tile
+        for (int q0 = wip * 16; q0 < QR; q0 += wpp * 16) {
+            const int q = q0 + c;
+            const bool qok = active && q < Lq;
+            float4 qf[DC], gf[DC];
+#pragma unroll
+            for (int ch = 0; ch < DC; ++ch) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
+                if (qok) {
+                    t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)q * p.q_rs) * p.ldq + hd * DH + ch * 16 + g * 4);
+                    u = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)q * p.do_rs) * p.lddo + hd * DH + ch * 16 + g * 4);
+                }
+                qf[ch] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+                gf[ch] = u;
+            }
+            floatx4v st[NKT], dp[NKT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                floatx4v a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+                if (kt * 16 < Lk) {
+#pragma unroll
+                    for (int ch = 0; ch < DC; ++ch) {
+                        const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                        const float4 vf = *reinterpret_cast<const float4*>(Vs + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[ch].x, a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, gf[ch].x, a2, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[ch].y, a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, gf[ch].y, a2, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[ch].z, a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, gf[ch].z, a2, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[ch].w, a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, gf[ch].w, a2, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kt * 16 + g * 4 + j >= Lk) a1[j] = -INFINITY;
+                    mx = fmaxf(mx, a1[j]);
+                }
+                st[kt] = a1; dp[kt] = a2;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float e = __expf(st[kt][j] - mx); st[kt][j] = e; sum += e; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = qok ? 1.0f / sum : 0.f;                   // padded query columns contribute nothing
+            const unsigned long long base = (((unsigned long long)n * p.H + hd) * Lq + (qok ? q : 0)) * (unsigned long long)Lk;
+            float delta = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = kt * 16 + g * 4 + j;
+                    const float pr = st[kt][j] * inv;
+                    const float mult = (p.drop_p > 0.f && key < Lk) ? qt_drop_mult(p.seed, base + key, p.drop_p, p.inv_keep) : 1.0f;
+                    const float dpr = dp[kt][j] * mult;                 // grad wrt the pre-dropout probability
+                    delta += dpr * pr;
+                    st[kt][j] = pr;
+                    dp[kt][j] = dpr;
+                    PT[key * LDQ + q] = pr * mult;                      // dropped P (forward value), for dV
+                }
+            delta += __shfl_xor(delta, 16, 64);
+            delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ds = st[kt][j] * (dp[kt][j] - delta);
+                    st[kt][j] = ds;
+                    ST[(kt * 16 + g * 4 + j) * LDQ + q] = ds;
+                }
+            floatx4v oacc[DC];
+#pragma unroll
+            for (int dt = 0; dt < DC; ++dt) oacc[dt] = floatx4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt * 16 >= Lk) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* krow = Ks + (kt * 16 + g * 4 + j) * LDK + c;
+#pragma unroll
+                    for (int dt = 0; dt < DC; ++dt)
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][j], krow[dt * 16], oacc[dt], 0, 0, 0);
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qo = q0 + g * 4 + j;
+                    if (qo < Lq) {
+                        float* drow = p.dq + ((long)n * p.dq_is + (long)qo * p.dq_rs) * p.lddq + hd * DH + c;
+#pragma unroll
+                        for (int dt = 0; dt < DC; ++dt) drow[dt * 16] = oacc[dt][j] * p.scale;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                // K|V dead; PT|ST complete
+        for (int idx = wip * 64 + lane; idx < QR * V4; idx += wpp * 64) {
+            const int qi = idx / V4, c4 = idx - qi * V4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
+            if (active && qi < Lq) {
+                t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)qi * p.q_rs) * p.ldq + hd * DH + c4 * 4);
+                u = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)qi * p.do_rs) * p.lddo + hd * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(Qs + qi * LDK + c4 * 4) = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+            *reinterpret_cast<float4*>(Gs + qi * LDK + c4 * 4) = u;
+        }
+        __syncthreads();
+        // ---------------- phase B: one wave per 16-key tile; MFMA k dimension = query index
+        for (int kt = wip; kt * 16 < Lk; kt += wpp) {
+            floatx4v av[DC], ak[DC];
+#pragma unroll
+            for (int dt = 0; dt < DC; ++dt) { av[dt] = floatx4v{0.f, 0.f, 0.f, 0.f}; ak[dt] = av[dt]; }
+            for (int qc = 0; qc < nqt; ++qc) {
+                const float4 pf = *reinterpret_cast<const float4*>(PT + (kt * 16 + c) * LDQ + qc * 16 + g * 4);
+                const float4 sf = *reinterpret_cast<const float4*>(ST + (kt * 16 + c) * LDQ + qc * 16 + g * 4);
+                const float pa[4] = {pf.x, pf.y, pf.z, pf.w}, sa[4] = {sf.x, sf.y, sf.z, sf.w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* grow = Gs + (qc * 16 + g * 4 + s) * LDK + c;
+                    const float* qrow = Qs + (qc * 16 + g * 4 + s) * LDK + c;
+#pragma unroll
+                    for (int dt = 0; dt < DC; ++dt) {
+                        av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], grow[dt * 16], av[dt], 0, 0, 0);
+                        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[s], qrow[dt * 16], ak[dt], 0, 0, 0);
+                    }
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = kt * 16 + g * 4 + j;
+                    if (key < Lk) {
+                        const long row = (long)kvn * p.kv_is + key;
+                        float* dkp = p.dk + row * p.lddk + hd * DH + c;
+                        float* dvp = p.dv + row * p.lddv + hd * DH + c;
+#pragma unroll
+                        for (int dt = 0; dt < DC; ++dt) {
+                            float kk = ak[dt][j], vv = av[dt][j];
+                            if (rep > 0) { kk += dkp[dt * 16]; vv += dvp[dt * 16]; }
+                            dkp[dt * 16] = kk; dvp[dt * 16] = vv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+static bool attn_mfma_ok(const AttnArgs& a, bool bwd) {
+    if (a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 80 || a.dh == 48 || a.dh == 112) return false;
+    if (a.Lk > 128) return false;
+    if (bwd && (a.Lq > 64 || a.n_items % a.n_kv != 0)) return false;
+    const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
+    if (!al) return false;
+    if (bwd && !(qt_aligned16(a.d_o) && a.lddo % 4 == 0)) return false;
+    return true;
+}
+static int nkt_bucket(int Lk) { const int t = (Lk + 15) / 16; return t <= 1 ? 1 : (t <= 4 ? 4 : (t <= 5 ? 5 : 8)); }
+
+template <int DC, int NKT>
+static int launch_fwd_mfma(const AttnArgs& a, hipStream_t st) {
+    const int nqt = (a.Lq + 15) / 16;
+    const int wpp = nqt >= 3 || NKT > 1 ? 4 : (nqt == 2 ? 2 : 1);
+    const int ppb = 4 / wpp;
+    const size_t lds = sizeof(float) * (size_t)ppb * 2 * (NKT * 16) * (DC * 16 + 4);
+    const long probs = (long)a.n_items * a.H;
+    const long blocks = (probs + ppb - 1) / ppb;
+    auto kern = qt_attn_fwd_mfma_kernel<DC, NKT>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a, wpp);
+    return 0;
+}
+template <int DC, int NKT>
+static int launch_bwd_mfma(const AttnArgs& a, hipStream_t st) {
+    const int nqt = (a.Lq + 15) / 16;
+    const int wpp = (nqt > 1 || NKT > 1) ? 4 : 1;
+    const int ppb = 4 / wpp;
+    const int LDK = DC * 16 + 4, KR = NKT * 16, QR = nqt * 16, LDQ = QR + 4;
+    const size_t per = (size_t)(2 * (KR > QR ? KR : QR)) * LDK + (size_t)2 * KR * LDQ;
+    const size_t lds = sizeof(float) * per * ppb;
+    if (lds > 160 * 1024) return 1;
+    const long probs = (long)a.n_kv * a.H;
+    const long blocks = (probs + ppb - 1) / ppb;
+    auto kern = qt_attn_bwd_mfma_kernel<DC, NKT>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a, wpp, nqt);
+    return 0;
+}
+#define QT_ATTN_DISPATCH(fn, a, st, rc)                                            \
+    do {                                                                           \
+        const int dc_ = (a).dh / 16, nk_ = nkt_bucket((a).Lk);                     \
+        rc = -1;                                                                   \
+        if (dc_ == 2) { if (nk_ == 1) rc = fn<2, 1>(a, st); else if (nk_ == 4) rc = fn<2, 4>(a, st); else if (nk_ == 5) rc = fn<2, 5>(a, st); else rc = fn<2, 8>(a, st); } \
+        else if (dc_ == 4) { if (nk_ == 1) rc = fn<4, 1>(a, st); else if (nk_ == 4) rc = fn<4, 4>(a, st); else if (nk_ == 5) rc = fn<4, 5>(a, st); else rc = fn<4, 8>(a, st); } \
+        else if (dc_ == 6) { if (nk_ == 1) rc = fn<6, 1>(a, st); else if (nk_ == 4) rc = fn<6, 4>(a, st); else if (nk_ == 5) rc = fn<6, 5>(a, st); else rc = fn<6, 8>(a, st); } \
+        else if (dc_ == 8) { if (nk_ == 1) rc = fn<8, 1>(a, st); else if (nk_ == 4) rc = fn<8, 4>(a, st); else if (nk_ == 5) rc = fn<8, 5>(a, st); else rc = fn<8, 8>(a, st); } \
+    } while (0)
+
 static int attn_block(int Lq, int Lk, int dh) {
     const long work = (long)Lq * Lk * dh;
     return work <= 14L * 14 * 128 ? 64 : 256;
@@ -214,6 +588,11 @@ extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, lo
     a.o = o; a.ldo = ldo; a.o_is = o_is; a.o_rs = o_rs;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
     a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    if (attn_mfma_ok(a, false)) {
+        int rc;
+        QT_ATTN_DISPATCH(launch_fwd_mfma, a, (hipStream_t)stream, rc);
+        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return QT_OK; }
+    }
     const int dp = dh + 1;
     const size_t lds = sizeof(float) * ((size_t)Lq * dp + (size_t)Lk * dp + (size_t)Lk * dh + (size_t)Lq * (Lk + 1));
     if (lds > 160 * 1024)
@@ -249,6 +628,11 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
     a.dq = dq; a.lddq = lddq; a.dq_is = dq_is; a.dq_rs = dq_rs; a.dk = dk; a.lddk = lddk; a.dv = dv; a.lddv = lddv;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
     a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    if (attn_mfma_ok(a, true) && qt_aligned16(dq) && qt_aligned16(dk) && qt_aligned16(dv)) {
+        int rc;
+        QT_ATTN_DISPATCH(launch_bwd_mfma, a, (hipStream_t)stream, rc);
+        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(mfma)"); return QT_OK; }
+    }
     const int dp = dh + 1;
     const size_t lds = sizeof(float) * (2 * (size_t)Lq * dp + 2 * (size_t)Lk * dp + 2 * (size_t)Lq * (Lk + 1));
     if (lds > 160 * 1024)
