@@ -17,6 +17,18 @@ from . import _lib
 
 LN_EPS = 1e-5
 
+# GEMM arithmetic.  'fp32'  : v_mfma_f32_32x32x2_f32 (exact fp32 products)
+#                   'f16x3' : three fp16 MFMAs per product on hi/lo-split operands (~fp32 accuracy, fp16 range)
+#                   'bf16x3': three bf16 MFMAs per product (~1.5e-5 relative, fp32 range)
+# Forward GEMMs see activations/weights (well inside fp16 range); backward GEMMs see gradients.
+# QT_GEMM=fp32 forces the exact-fp32 kernels everywhere.
+import os as _os
+if _os.environ.get('QT_GEMM', '').lower() == 'fp32':
+    precision = {'fwd': 'fp32', 'bwd': 'fp32'}
+else:
+    precision = {'fwd': 'f16x3', 'bwd': 'bf16x3'}
+_HALF_TYPE = {'f16x3': 0, 'bf16x3': 1}
+
 
 # --------------------------------------------------------------------------- #
 # plumbing
@@ -114,8 +126,8 @@ def _launch(family: str, work: float, detail, fn):
 def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, out: Optional[Tensor] = None,
          bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: bool = False,
          mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
-         accumulate: bool = False, alpha: float = 1.0, split_k: int = 0) -> Tensor:
-    """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32."""
+         accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, mode: str = 'fp32') -> Tensor:
+    """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3."""
     a, b = as2d(a), as2d(b)
     _dev(a, b, bias, add, mask_src, out)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -133,7 +145,21 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     if mask_src is not None:
         mask_src = as2d(mask_src)
         assert mask_src.shape == (M, N)
-    rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b)), lambda: _lib.load().qt_gemm_f32(
+    tail = (int(trans_a), int(trans_b), M, N, K, float(alpha),
+            _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
+            _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
+            _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
+            float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k))
+    if mode != 'fp32':
+        rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b), mode),
+                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail))
+        if rc == 0:
+            return out
+        if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
+            _lib.check(rc, 'qt_gemm_x3')
+        if timer is not None:
+            timer.records.pop()
+    rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b), 'fp32'), lambda: _lib.load().qt_gemm_f32(
         _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
         _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
         _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
@@ -185,7 +211,7 @@ class LinearFn(torch.autograd.Function):
                 residual: Optional[Tensor], grad_premasked: bool):
         shape = x.shape
         x2 = as2d(x)
-        y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed)
+        y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'])
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.cfg = (relu, drop_p, seed, bias is not None, residual is not None, grad_premasked, shape)
         return y.reshape(*shape[:-1], weight.shape[0])
@@ -199,9 +225,9 @@ class LinearFn(torch.autograd.Function):
             g = mask_grad(g, y if relu else None, drop_p, seed)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(g, weight, trans_b=False).reshape(shape)
+            dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
         if ctx.needs_input_grad[1]:
-            dw = gemm(g, x2, trans_a=True, trans_b=False)          # [N_out, K_in] = g^T x
+            dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'])          # [N_out, K_in] = g^T x
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(g)
         if has_res and ctx.needs_input_grad[6]:

@@ -46,6 +46,31 @@ def test_gemm_layouts(ops, M, N, K, ta, tb):
         assert rel(out, ref) < 2e-5, (split,)
 
 
+@pytest.mark.parametrize('mode,tol', [('f16x3', 2e-6), ('bf16x3', 6e-5)])
+@pytest.mark.parametrize('M,N,K', [(256, 768, 768), (1000, 384, 128), (2048, 2304, 768), (300, 200, 100), (3840, 768, 1024), (129, 130, 36)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_split_precision(ops, mode, tol, M, N, K, ta, tb):
+    """Three-MFMA split products: fp16 parts stay at fp32-level accuracy, bf16 parts at ~1e-5."""
+    a = rnd(*((K, M) if ta else (M, K)), seed=1)
+    b = rnd(*((N, K) if tb else (K, N)), seed=2, scale=0.05)        # weight-like magnitudes (fp16 lo part goes subnormal)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    for split in (1, 0):
+        out = ops.gemm(a, b, trans_a=ta, trans_b=tb, split_k=split, mode=mode)
+        assert rel(out, ref) < tol, (split, rel(out, ref))
+    bias = rnd(N, seed=3)
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, relu=True, mode=mode)
+    assert rel(out, (ref + bias.double()).clamp_min(0)) < tol
+
+
+def test_gemm_bf16x3_keeps_gradient_range(ops):
+    """Backward operands are gradients of magnitude ~1e-8: bf16 parts keep them, fp16 parts would flush."""
+    a = rnd(512, 256, seed=4, scale=1e-8)
+    b = rnd(384, 256, seed=5)
+    ref = a.double() @ b.double().t()
+    assert rel(ops.gemm(a, b, mode='bf16x3'), ref) < 6e-5
+    assert rel(ops.gemm(a, b, mode='f16x3'), ref) > 1e-3
+
+
 def test_gemm_strided_views_and_epilogues(ops):
     M, N, K = 300, 200, 96
     big_a, big_b = rnd(M, K + 32, seed=3), rnd(N, K + 16, seed=4)
