@@ -28,6 +28,7 @@
 // thread, so that it can be written to the same [row][k] image without a
 // scatter.
 #include "qt_common.h"
+#include <type_traits>
 
 #define SBK 32
 #define SLD 40            // 16-bit elements per LDS row (32 + 8 pad = 80 B)
@@ -48,6 +49,7 @@ struct GemmArgs {          // identical to gemm.hip
     int split_k;
     int k_per_split;
     int tiles_n;
+    int tiles_m;
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -82,7 +84,15 @@ __global__ __launch_bounds__(256, 2) void qt_gemm_x3_kernel(GemmArgs p) {
     const int nwg = gridDim.x, orig = blockIdx.x;                  // XCD-aware tile order (see gemm.hip)
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tile_m = wgid / p.tiles_n, tile_n = wgid - tile_m * p.tiles_n;
+    // Inside an XCD's contiguous chunk, walk groups of GM M-tiles: M fastest, then N.  The 64
+    // workgroups resident on an XCD then cover an ~8x8 window of tiles, so each A panel and each
+    // B panel fetched into that XCD's 4 MiB L2 is shared by 8 workgroups (a plain N-fastest walk
+    // needs every B panel at once: 7 MB at N=2304, 49 % L2 hits measured).
+    constexpr int GM = 8;
+    const int group = wgid / (GM * p.tiles_n);
+    const int gm_rows = min(GM, p.tiles_m - group * GM);
+    const int within = wgid - group * (GM * p.tiles_n);
+    const int tile_n = within / gm_rows, tile_m = group * GM + (within - tile_n * gm_rows);
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -95,34 +105,52 @@ __global__ __launch_bounds__(256, 2) void qt_gemm_x3_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float ra[16], rb[16];                                          // one tile's worth of fp32 per thread, per operand
+    // two register sets: tile t+1 (loaded last iteration) and tile t+2 (issued this iteration)
+    float ra0[16], rb0[16], ra1[16], rb1[16];
 
+    // Addressing is hoisted: a wave-uniform base (kernel argument + k0) plus a per-thread 32-bit
+    // byte offset computed once, so a load in the loop is one instruction and no 64-bit VALU math.
     // K-contiguous operand: 4 x float4, thread -> (row = idx>>3, k-quad = idx&7)
-    auto load_kc = [&](const float* base, long ld, int row0, int rows_total, int k0, float* dst) {
+    // K-slow operand: 16 coalesced dwords, thread -> (col = tid&127, k-octets 2*(tid>>7) + {0,1})
+    unsigned offA[4], offB[4];
+    {
+        const int colA = min(m0 + (tid & 127), p.M - 1), colB = min(n0 + (tid & 127), p.N - 1);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = tid + it * 256;
             const int row = idx >> 3, kq = idx & 7;
-            const int gr = min(row0 + row, rows_total - 1);
-            const int gk = k0 + kq * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < kend) v = *reinterpret_cast<const float4*>(base + (long)gr * ld + gk);   // K % 4 == 0 (host check)
+            offA[it] = TA ? 0u : (unsigned)(((long)min(m0 + row, p.M - 1) * p.lda + kq * 4) * 4);
+            offB[it] = TB ? (unsigned)(((long)min(n0 + row, p.N - 1) * p.ldb + kq * 4) * 4) : 0u;
+        }
+        if (TA) offA[0] = (unsigned)(((long)((tid >> 7) * 16) * p.lda + colA) * 4);
+        if (!TB) offB[0] = (unsigned)(((long)((tid >> 7) * 16) * p.ldb + colB) * 4);
+    }
+    // `full` is a compile-time tag: the hot path (whole BK inside [kbeg,kend)) is straight-line
+    // loads; only the last, partial tile of a K range takes the predicated build.
+    auto load_kc = [&](const float* base, const unsigned (&off)[4], int k0, auto full, float (&dst)[16]) {
+        const char* b = reinterpret_cast<const char*>(base + k0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            float4 v;
+            if constexpr (decltype(full)::value) {
+                v = *reinterpret_cast<const float4*>(b + off[it]);
+            } else {
+                v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + (int)(((tid + it * 256) & 7) * 4) < kend) v = *reinterpret_cast<const float4*>(b + off[it]);
+            }
             dst[it * 4 + 0] = v.x; dst[it * 4 + 1] = v.y; dst[it * 4 + 2] = v.z; dst[it * 4 + 3] = v.w;
         }
     };
-    // K-slow operand: 16 coalesced dwords, thread -> (col = tid&127, k-octets 2*(tid>>7) + {0,1})
-    auto load_ks = [&](const float* base, long ld, int col0, int cols_total, int k0, float* dst) {
-        const int col = tid & 127, oh = tid >> 7;
-        const int gc = min(col0 + col, cols_total - 1);
+    auto load_ks = [&](const float* base, long ld, const unsigned (&off)[4], int k0, auto full, float (&dst)[16]) {
+        const char* b = reinterpret_cast<const char*>(base + (long)k0 * ld) + off[0];
+        const int kt = k0 + (tid >> 7) * 16;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int gk = k0 + (oh * 2 + e) * 8 + j;
-                dst[e * 8 + j] = gk < kend ? base[(long)gk * ld + gc] : 0.f;
-            }
+        for (int j = 0; j < 16; ++j) {
+            if constexpr (decltype(full)::value) dst[j] = *reinterpret_cast<const float*>(b + (long)j * ld * 4);
+            else dst[j] = (kt + j < kend) ? *reinterpret_cast<const float*>(b + (long)j * ld * 4) : 0.f;
+        }
     };
-    auto store_kc = [&](u16* hi_img, u16* lo_img, const float* src) {
+    auto store_kc = [&](u16* hi_img, u16* lo_img, const float (&src)[16]) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = tid + it * 256;
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void qt_gemm_x3_kernel(GemmArgs p) {
             *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
         }
     };
-    auto store_ks = [&](u16* hi_img, u16* lo_img, const float* src) {
+    auto store_ks = [&](u16* hi_img, u16* lo_img, const float (&src)[16]) {
         const int col = tid & 127, oh = tid >> 7;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -153,23 +181,21 @@ __global__ __launch_bounds__(256, 2) void qt_gemm_x3_kernel(GemmArgs p) {
             *reinterpret_cast<uint4*>(lo_img + col * SLD + (oh * 2 + e) * 8) = vl;
         }
     };
-    auto gload = [&](int k0) {
-        if (TA) load_ks(p.A, p.lda, m0, p.M, k0, ra); else load_kc(p.A, p.lda, m0, p.M, k0, ra);
-        if (TB) load_kc(p.B, p.ldb, n0, p.N, k0, rb); else load_ks(p.B, p.ldb, n0, p.N, k0, rb);
+    auto gload = [&](int k0, float (&xa)[16], float (&xb)[16]) {
+        if (k0 + SBK <= kend) {                                     // wave-uniform
+            if (TA) load_ks(p.A, p.lda, offA, k0, std::true_type{}, xa); else load_kc(p.A, offA, k0, std::true_type{}, xa);
+            if (TB) load_kc(p.B, offB, k0, std::true_type{}, xb); else load_ks(p.B, p.ldb, offB, k0, std::true_type{}, xb);
+        } else {
+            if (TA) load_ks(p.A, p.lda, offA, k0, std::false_type{}, xa); else load_kc(p.A, offA, k0, std::false_type{}, xa);
+            if (TB) load_kc(p.B, offB, k0, std::false_type{}, xb); else load_ks(p.B, p.ldb, offB, k0, std::false_type{}, xb);
+        }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const float (&xa)[16], const float (&xb)[16]) {
         u16* b0 = smem + buf * (4 * STILE);
-        if (TA) store_ks(b0, b0 + STILE, ra); else store_kc(b0, b0 + STILE, ra);
-        if (TB) store_kc(b0 + 2 * STILE, b0 + 3 * STILE, rb); else store_ks(b0 + 2 * STILE, b0 + 3 * STILE, rb);
+        if (TA) store_ks(b0, b0 + STILE, xa); else store_kc(b0, b0 + STILE, xa);
+        if (TB) store_kc(b0 + 2 * STILE, b0 + 3 * STILE, xb); else store_ks(b0 + 2 * STILE, b0 + 3 * STILE, xb);
     };
-
-    const int nk = (kend - kbeg + SBK - 1) / SBK;
-    if (nk > 0) { gload(kbeg); sstore(0); }
-    __syncthreads();
-
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) gload(kbeg + (t + 1) * SBK);
+    auto compute = [&](int cur) {
         const u16* b0 = smem + cur * (4 * STILE);
         const u16 *sAh = b0, *sAl = b0 + STILE, *sBh = b0 + 2 * STILE, *sBl = b0 + 3 * STILE;
 #pragma unroll
@@ -196,7 +222,25 @@ __global__ __launch_bounds__(256, 2) void qt_gemm_x3_kernel(GemmArgs p) {
                     acc[i][j] = mma<HT>(ah[i], bh[j], acc[i][j]);
                 }
         }
-        if (t + 1 < nk) sstore(cur ^ 1);
+    };
+
+    // Pipeline: while tile t feeds the MFMAs from LDS, tile t+1 sits in one register set and
+    // the loads of tile t+2 are in flight into the other, so every load has ~2 iterations to land.
+    const int nk = (kend - kbeg + SBK - 1) / SBK;
+    if (nk > 0) { gload(kbeg, ra0, rb0); sstore(0, ra0, rb0); }
+    if (nk > 1) gload(kbeg + SBK, ra0, rb0);                        // tile 1 -> set 0
+    __syncthreads();
+    for (int t = 0; t < nk; t += 2) {
+        // even step: compute tile t (buf 0); set 0 holds tile t+1; fetch tile t+2 into set 1
+        if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra1, rb1);
+        compute(0);
+        if (t + 1 < nk) sstore(1, ra0, rb0);
+        __syncthreads();
+        if (t + 1 >= nk) break;
+        // odd step: compute tile t+1 (buf 1); set 1 holds tile t+2; fetch tile t+3 into set 0
+        if (t + 3 < nk) gload(kbeg + (t + 3) * SBK, ra0, rb0);
+        compute(1);
+        if (t + 2 < nk) sstore(0, ra1, rb1);
         __syncthreads();
     }
 
@@ -259,6 +303,11 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     // K-contiguous operands are staged with 16-byte loads
     if (!transA && !(qt_aligned16(A) && lda % 4 == 0 && K % 4 == 0)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: A not 16-byte aligned");
     if (transB && !(qt_aligned16(B) && ldb % 4 == 0 && K % 4 == 0)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: B not 16-byte aligned");
+    {   // per-thread offsets are 32-bit byte offsets from a wave-uniform base
+        const long spanA = transA ? ((long)32 * lda + M) : ((long)M * lda + 32);
+        const long spanB = transB ? ((long)N * ldb + 32) : ((long)32 * ldb + N);
+        if (spanA * 4 >= (1L << 32) || spanB * 4 >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: operand spans more than 4 GiB");
+    }
     if ((long)M * N < 128L * 128L || M < 64 || N < 64) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: problem too small for the 128x128 tile");
     hipStream_t st = (hipStream_t)stream;
     GemmArgs a;
@@ -268,15 +317,24 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
     const long tiles = (long)tiles_m * tiles_n;
-    a.tiles_n = tiles_n;
+    a.tiles_n = tiles_n; a.tiles_m = tiles_m;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     if (split_k <= 0) {
+        // 512 workgroups are resident at once (2 per CU).  Choose the split whose grid wastes the
+        // least of its last round; ties go to the larger split (shorter tail per workgroup).
         split_k = 1;
-        if (plain_epilogue && tiles < 384 && K >= 16 * SBK) {      // 2 workgroups/CU x 256 CUs: fill the chip
-            const long want = (512 + tiles - 1) / tiles;
-            const long maxs = K / (8 * SBK);
-            split_k = (int)(want < maxs ? want : maxs);
-            if (split_k < 1) split_k = 1;
+        if (plain_epilogue && tiles < 1024 && K >= 16 * SBK) {
+            const long slots = 512;
+            long maxs = K / (8 * SBK);
+            if (maxs > 32) maxs = 32;
+            double best = -1.0;
+            for (long s = 1; s <= maxs; ++s) {
+                const long blocks = tiles * s;
+                const long rounds = (blocks + slots - 1) / slots;
+                double eff = (double)blocks / (double)(rounds * slots);
+                if (s > 1) eff *= 0.97;                             // atomics + memset are not free
+                if (eff >= best - 1e-9) { best = eff; split_k = (int)s; }
+            }
         }
     }
     QT_CHECK_ARG(split_k == 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
