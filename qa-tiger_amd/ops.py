@@ -27,7 +27,7 @@ if _os.environ.get('QT_GEMM', '').lower() == 'fp32':
     precision = {'fwd': 'fp32', 'bwd': 'fp32'}
 else:
     precision = {'fwd': 'f16x3', 'bwd': 'bf16x3'}
-_HALF_TYPE = {'f16x3': 0, 'bf16x3': 1}
+_HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'f16x3_t128': 16, 'bf16x3_t128': 17, 'f16x3_t256': 32, 'bf16x3_t256': 33}   # _tNNN: force a tile (A/B testing)
 
 
 # --------------------------------------------------------------------------- #
