@@ -285,16 +285,52 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
     }
 
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // At K = 768 a tile has only 24 BK steps, so the epilogue's instruction count matters: the common
+    // cases (bias [+ReLU] store, or split-K atomics) take a lean path with one row pointer per output row;
+    // residual / mask / dropout / accumulate take the general path.
     const bool first_split = (blockIdx.y == 0);
+    const int mrow0 = m0 + wm * (WMT * 32) + 4 * h;
+    const int ncol0 = n0 + wn * (WNT * 32) + r;
+    const bool lean = !p.add_src && !p.mask_src && p.drop_p == 0.f && !p.accumulate;
+    if (lean) {
+        const bool atomic = p.split_k > 1;
+        const bool do_relu = p.relu != 0;
+        float bias_v[WNT];
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int n = ncol0 + j * 32;
+            bias_v[j] = (p.bias && first_split && n < p.N) ? p.bias[n] : 0.f;
+        }
+        static_for<WMT>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mrow0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    float* crow = p.C + (long)m * p.ldc + ncol0;
+                    static_for<WNT>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        if (ncol0 + j * 32 < p.N) {
+                            float v = p.alpha * acc[i][j][e] + bias_v[j];
+                            if (atomic) atomicAdd(crow + j * 32, v);
+                            else { if (do_relu) v = fmaxf(v, 0.f); crow[j * 32] = v; }
+                        }
+                    });
+                }
+            }
+        });
+        return;
+    }
     static_for<WMT>([&](auto I) {
         static_for<WNT>([&](auto J) {
             constexpr int i = decltype(I)::value, j = decltype(J)::value;
-            const int n = n0 + wn * (WNT * 32) + j * 32 + r;
+            const int n = ncol0 + j * 32;
             if (n < p.N) {
                 const float bias_v = (p.bias && first_split) ? p.bias[n] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * (WMT * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int m = mrow0 + i * 32 + (e & 3) + 8 * (e >> 2);
                     if (m >= p.M) continue;
                     float v = p.alpha * acc[i][j][e] + bias_v;
                     float* dst = p.C + (long)m * p.ldc + n;
