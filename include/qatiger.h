@@ -47,13 +47,15 @@ int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float
 /* Same contract as qt_gemm_f32, computed with three 16-bit MFMAs per product on operands split
  * on the fly into hi+lo parts (half_type 0: fp16 parts, ~fp32-accurate, operands must be inside
  * fp16 range — forward GEMMs; 1: bf16 parts, ~1.5e-5 relative, full exponent range — backward GEMMs).
- * Returns -4 without touching C when the shape or alignment does not fit its 128x128 tile;
- * callers then use qt_gemm_f32. */
+ * a_colsum (nullable, transA only): a_colsum[m] = sum_k A[k,m] — the bias gradient of a Linear layer
+ * computed while the dW GEMM streams dY (A = dY given as [rows, N_out]).
+ * Returns -4 without touching C or a_colsum when the shape or alignment does not fit its tiles;
+ * callers then use qt_gemm_f32 (+ qt_colsum). */
 int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N, int K, float alpha,
                const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                const float* bias, const float* add_src, long ld_add, int relu,
                const float* mask_src, long ld_mask, float mask_scale,
-               float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum);
 
 /* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
  * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward

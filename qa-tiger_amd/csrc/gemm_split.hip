@@ -50,6 +50,7 @@ struct GemmArgs {          // identical to gemm.hip
     int k_per_split;
     int tiles_n;
     int tiles_m;
+    float* a_colsum;          // transA only: a_colsum[m] += sum_k A[k,m]  (bias gradient riding on the dW GEMM)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
         }
     };
+    float csum = 0.f;                                               // this thread's share of a_colsum (TA only)
+    const bool do_csum = TA && p.a_colsum != nullptr && tile_n == 0;
     auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src) {
         constexpr int KN = sizeof(src) / sizeof(src[0]);
         const int col = tid % edge, kb = (tid / edge) * KN;
@@ -224,7 +227,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     };
     auto sstore = [&](int buf, const auto& xa, const auto& xb) {
         u16* b0 = smem + buf * STAGE;
-        if (TA) store_ks(b0, b0 + A_IMG, BM, xa); else store_kc(b0, b0 + A_IMG, xa);
+        if (TA) {
+            store_ks(b0, b0 + A_IMG, BM, xa);
+            if (do_csum) {                                          // K-tail and out-of-range rows were loaded as zeros
+                constexpr int KN = sizeof(xa) / sizeof(xa[0]);
+#pragma unroll
+                for (int j = 0; j < KN; ++j) csum += xa[j];
+            }
+        } else store_kc(b0, b0 + A_IMG, xa);
         if (TB) store_kc(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, xb); else store_ks(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, BN, xb);
     };
     auto compute = [&](int cur) {
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
     }
 
+    if (do_csum && m0 + (tid % BM) < p.M) atomicAdd(p.a_colsum + m0 + (tid % BM), csum);
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // At K = 768 a tile has only 24 BK steps, so the epilogue's instruction count matters: the common
     // cases (bias [+ReLU] store, or split-K atomics) take a lean path with one row pointer per output row;
@@ -375,8 +386,9 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                           const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
-                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_x3: bad problem");
+    QT_CHECK_ARG(!a_colsum || transA, "qt_gemm_x3: a_colsum needs transA (A given as [K,M])");
     const int force = half_type >> 4;
     half_type &= 15;
     QT_CHECK_ARG(half_type == 0 || half_type == 1, "qt_gemm_x3: half_type must be 0 (fp16) or 1 (bf16)");
@@ -397,6 +409,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
+    a.a_colsum = a_colsum;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
 
@@ -436,6 +449,10 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.split_k = split_k; a.k_per_split = kps;
     if (split_k > 1 && !accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
+    }
+    if (a_colsum) {
+        hipError_t e = hipMemsetAsync(a_colsum, 0, sizeof(float) * (size_t)M, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
     }
     QT_CHECK_ARG(tiles < (1L << 31), "qt_gemm_x3: grid too large");

@@ -126,7 +126,8 @@ def _launch(family: str, work: float, detail, fn):
 def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, out: Optional[Tensor] = None,
          bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: bool = False,
          mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
-         accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, mode: str = 'fp32') -> Tensor:
+         accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, mode: str = 'fp32',
+         a_colsum: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3."""
     a, b = as2d(a), as2d(b)
     _dev(a, b, bias, add, mask_src, out)
@@ -152,7 +153,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
             float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k))
     if mode != 'fp32':
         rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b), mode),
-                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail))
+                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum)))
         if rc == 0:
             return out
         if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
@@ -166,6 +167,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
         float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k)))
     _lib.check(rc, 'qt_gemm_f32')
+    if a_colsum is not None:                           # the fp32 kernel has no fused column sum
+        _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), 0), 'qt_colsum')
     return out
 
 
@@ -226,9 +229,12 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'])          # [N_out, K_in] = g^T x
-        if has_bias and ctx.needs_input_grad[2]:
+            if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
+                db = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
+            dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db)   # [N_out, K_in] = g^T x
+        elif want_db:
             db = colsum(g)
         if has_res and ctx.needs_input_grad[6]:
             dres = g.reshape(*shape[:-1], weight.shape[0]) if not (relu or drop_p > 0.0) else None

@@ -62,6 +62,18 @@ def test_gemm_split_precision(ops, mode, tol, M, N, K, ta, tb):
     assert rel(out, (ref + bias.double()).clamp_min(0)) < tol
 
 
+@pytest.mark.parametrize('M,N,K', [(768, 768, 30720), (2304, 512, 70000), (130, 200, 1000), (384, 768, 960)])
+def test_gemm_fused_bias_gradient(ops, M, N, K):
+    """a_colsum: the column sums of the K-slow A operand (= bias gradient) computed inside the dW GEMM."""
+    g = rnd(K, M, seed=6, scale=1e-3)
+    x = rnd(K, N, seed=7)
+    for mode in ('bf16x3', 'fp32'):
+        db = torch.full((M,), 7.0, device=DEV)
+        dw = ops.gemm(g, x, trans_a=True, trans_b=False, mode=mode, a_colsum=db)
+        assert rel(dw, g.double().t() @ x.double()) < 6e-5
+        assert rel(db, g.double().sum(0)) < 1e-5
+
+
 def test_gemm_bf16x3_keeps_gradient_range(ops):
     """Backward operands are gradients of magnitude ~1e-8: bf16 parts keep them, fp16 parts would flush."""
     a = rnd(512, 256, seed=4, scale=1e-8)
