@@ -62,19 +62,23 @@ int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N
  * math path) at modules.py:217-221, 338, 562, 688, 698.
  * Element (item n, row i, col c) of q is q[(n*q_is + i*q_rs)*ldq + c]; key/value rows
  * of kv item m are rows m*kv_is .. m*kv_is+Lk-1.  Query item n attends to kv item
- * (n + kv_shift) % n_kv.  Head h uses columns h*dh .. h*dh+dh-1. */
+ * (n + kv_shift) % n_kv.  Head h uses columns h*dh .. h*dh+dh-1.
+ * Short sequences (Lk <= 128) keep K/V resident in LDS; longer ones stream K/V in chunks with an
+ * online softmax and need `lse` [n_items,H,Lq] (written by fwd), and in bwd the forward output
+ * `o_fwd` (same addressing as d_o) plus a workspace `delta_ws` [n_items,H,Lq]. */
 int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
                 const float* k, long ldk, const float* v, long ldv, long kv_is,
                 float* o, long ldo, long o_is, long o_rs,
                 int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
-                float scale, float drop_p, unsigned long long seed);
+                float scale, float drop_p, unsigned long long seed, float* lse);
 int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
                 const float* k, long ldk, const float* v, long ldv, long kv_is,
                 const float* d_o, long lddo, long do_is, long do_rs,
                 float* dq, long lddq, long dq_is, long dq_rs,
                 float* dk, long lddk, float* dv, long lddv,
                 int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
-                float scale, float drop_p, unsigned long long seed);
+                float scale, float drop_p, unsigned long long seed,
+                const float* o_fwd, const float* lse, float* delta_ws);
 
 /* y = LayerNorm(sum_i sx[i] * dropout_i(x[i])) (+ optional ReLU on y); n_add <= 4.
  * Replaces modules.py:223-229, 233-235, 344-346, 603, 612, 713-716.

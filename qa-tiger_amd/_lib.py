@@ -48,9 +48,9 @@ _i, _l, _f, _u64 = C.c_int, C.c_long, C.c_float, C.c_ulonglong
 SIGNATURES = {
     'qt_gemm_f32': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
     'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p],
-    'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64],
+    'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
-                    _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64],
+                    _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],
     'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
     'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],

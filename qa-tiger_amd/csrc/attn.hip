@@ -33,6 +33,10 @@ struct AttnArgs {
     float* dq; long lddq, dq_is, dq_rs;
     float* dk; long lddk;
     float* dv; long lddv;
+    // streaming (long-sequence) path
+    float* lse;              // [n_items, H, Lq]  log-sum-exp of the scaled scores (written by fwd, read by bwd)
+    const float* o_fwd;      // forward output, same addressing as d_o (bwd: delta = rowsum(dO * O))
+    float* delta;            // [n_items, H, Lq] workspace
 };
 
 __device__ inline int lds_pad(int dh) { return dh + 1; }   // odd row stride: conflict-free column walks
@@ -520,10 +524,380 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
     }
 }
 
+
+// ============================================================================
+// Streaming path for long sequences (BASELINE config 4: T = 300, d_h = 128)
+// ============================================================================
+// Keys/values no longer fit in LDS, so they are streamed in chunks of 64 with an online softmax
+// (running max m, running sum l, O rescaled per chunk).  Same MFMA fragments as the resident kernels.
+// Backward is the two-kernel form: dQ per query tile (streams K/V), dK/dV per key tile (streams
+// Q/dO), both recomputing P = exp(s - lse) from the forward's log-sum-exp, so nothing is atomic.
+#define SKC 64      // keys (or queries) per streamed chunk
+
+template <int DC>
+__global__ __launch_bounds__(256) void qt_attn_fwd_stream_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DH = DC * 16, LDK = DH + 4, V4 = DH / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int n = blockIdx.x / p.H, hd = blockIdx.x - n * p.H;
+    const int kvn = (n + p.kv_shift) % p.n_kv;
+    const int Lq = p.Lq, Lk = p.Lk;
+    const int q0 = (blockIdx.y * 4 + wave) * 16;
+    const bool wave_on = q0 < Lq;
+    const int q = q0 + c;
+    const bool qok = wave_on && q < Lq;
+    float* Ks = lds;
+    float* Vs = Ks + SKC * LDK;
+    float4 qf[DC];
+#pragma unroll
+    for (int ch = 0; ch < DC; ++ch) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qok) t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)q * p.q_rs) * p.ldq + hd * DH + ch * 16 + g * 4);
+        qf[ch] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+    }
+    floatx4v oacc[DC];
+#pragma unroll
+    for (int dt = 0; dt < DC; ++dt) oacc[dt] = floatx4v{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;          // per query column (lane c); l is this lane's partial over its keys
+    const unsigned long long base = (((unsigned long long)n * p.H + hd) * Lq + (qok ? q : 0)) * (unsigned long long)Lk;
+    for (int kc0 = 0; kc0 < Lk; kc0 += SKC) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < SKC * V4; idx += 256) {
+            const int j = idx / V4, c4 = idx - j * V4;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (kc0 + j < Lk) {
+                const long row = (long)kvn * p.kv_is + kc0 + j;
+                kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk;
+            *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+        floatx4v st[4];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            floatx4v acc = {0.f, 0.f, 0.f, 0.f};
+            if (kc0 + kt * 16 < Lk) {
+#pragma unroll
+                for (int ch = 0; ch < DC; ++ch) {
+                    const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[ch].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[ch].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[ch].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[ch].w, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (kc0 + kt * 16 + g * 4 + j >= Lk) acc[j] = -INFINITY;
+                cm = fmaxf(cm, acc[j]);
+            }
+            st[kt] = acc;
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float m_new = fmaxf(m_run, cm);                         // finite: every chunk holds a valid key
+        const float alpha = __expf(m_run - m_new);                    // 0 on the first chunk
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float e = __expf(st[kt][j] - m_new);
+                lsum += e;
+                const int key = kc0 + kt * 16 + g * 4 + j;
+                if (p.drop_p > 0.f && key < Lk) e *= qt_drop_mult(p.seed, base + key, p.drop_p, p.inv_keep);
+                st[kt][j] = e;
+            }
+        l_run = l_run * alpha + lsum;
+        // O rows are queries 4g+j of this tile; their rescale factor lives in lane (c = 4g+j)
+        float al[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) al[j] = __shfl(alpha, g * 4 + j, 64);
+#pragma unroll
+        for (int dt = 0; dt < DC; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oacc[dt][j] *= al[j];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kc0 + kt * 16 >= Lk) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* vrow = Vs + (kt * 16 + g * 4 + j) * LDK + c;
+#pragma unroll
+                for (int dt = 0; dt < DC; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][j], vrow[dt * 16], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_on) return;
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (g == 0 && qok && p.lse) p.lse[((long)n * p.H + hd) * Lq + q] = m_run + __logf(l_tot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float iv = __shfl(inv, g * 4 + j, 64);
+        const int qo = q0 + g * 4 + j;
+        if (qo < Lq) {
+            float* orow = p.o + ((long)n * p.o_is + (long)qo * p.o_rs) * p.ldo + hd * DH + c;
+#pragma unroll
+            for (int dt = 0; dt < DC; ++dt) orow[dt * 16] = oacc[dt][j] * iv;
+        }
+    }
+}
+
+// dQ (and delta = rowsum(dO*O)) per 16-query tile; streams K/V chunks.
+template <int DC>
+__global__ __launch_bounds__(256) void qt_attn_bwd_dq_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DH = DC * 16, LDK = DH + 4, V4 = DH / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int n = blockIdx.x / p.H, hd = blockIdx.x - n * p.H;
+    const int kvn = (n + p.kv_shift) % p.n_kv;
+    const int Lq = p.Lq, Lk = p.Lk;
+    const int q0 = (blockIdx.y * 4 + wave) * 16;
+    const bool wave_on = q0 < Lq;
+    const int q = q0 + c;
+    const bool qok = wave_on && q < Lq;
+    float* Ks = lds;
+    float* Vs = Ks + SKC * LDK;
+    float4 qf[DC], gf[DC];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < DC; ++ch) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t, w = t;
+        if (qok) {
+            t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)q * p.q_rs) * p.ldq + hd * DH + ch * 16 + g * 4);
+            const long orow = ((long)n * p.do_is + (long)q * p.do_rs) * p.lddo + hd * DH + ch * 16 + g * 4;
+            u = *reinterpret_cast<const float4*>(p.d_o + orow);
+            w = *reinterpret_cast<const float4*>(p.o_fwd + orow);
+        }
+        qf[ch] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+        gf[ch] = u;
+        dpart += u.x * w.x + u.y * w.y + u.z * w.z + u.w * w.w;
+    }
+    dpart += __shfl_xor(dpart, 16, 64);
+    dpart += __shfl_xor(dpart, 32, 64);
+    const float delta = dpart;
+    const float lse = qok ? p.lse[((long)n * p.H + hd) * Lq + q] : 0.f;
+    if (g == 0 && qok) p.delta[((long)n * p.H + hd) * Lq + q] = delta;
+    floatx4v oacc[DC];
+#pragma unroll
+    for (int dt = 0; dt < DC; ++dt) oacc[dt] = floatx4v{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long base = (((unsigned long long)n * p.H + hd) * Lq + (qok ? q : 0)) * (unsigned long long)Lk;
+    for (int kc0 = 0; kc0 < Lk; kc0 += SKC) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < SKC * V4; idx += 256) {
+            const int j = idx / V4, c4 = idx - j * V4;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (kc0 + j < Lk) {
+                const long row = (long)kvn * p.kv_is + kc0 + j;
+                kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk;
+            *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kc0 + kt * 16 >= Lk) continue;
+            floatx4v a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < DC; ++ch) {
+                const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                const float4 vf = *reinterpret_cast<const float4*>(Vs + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[ch].x, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, gf[ch].x, a2, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[ch].y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, gf[ch].y, a2, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[ch].z, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, gf[ch].z, a2, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[ch].w, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, gf[ch].w, a2, 0, 0, 0);
+            }
+            floatx4v ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = kc0 + kt * 16 + g * 4 + j;
+                const float pr = (qok && key < Lk) ? __expf(a1[j] - lse) : 0.f;
+                const float mult = (p.drop_p > 0.f && key < Lk) ? qt_drop_mult(p.seed, base + key, p.drop_p, p.inv_keep) : 1.0f;
+                ds[j] = pr * (a2[j] * mult - delta);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* krow = Ks + (kt * 16 + g * 4 + j) * LDK + c;
+#pragma unroll
+                for (int dt = 0; dt < DC; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[j], krow[dt * 16], oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int qo = q0 + g * 4 + j;
+        if (qo < Lq) {
+            float* drow = p.dq + ((long)n * p.dq_is + (long)qo * p.dq_rs) * p.lddq + hd * DH + c;
+#pragma unroll
+            for (int dt = 0; dt < DC; ++dt) drow[dt * 16] = oacc[dt][j] * p.scale;
+        }
+    }
+}
+
+// dK/dV per 16-key tile; streams chunks of (scaled) Q and dO of every query item that attends to
+// this kv item.  Orientation S[q][key] = Q·K^T so that P (rows = queries on (g,j), column = key on
+// the lane) is directly the A operand of dV = P^T·dO and dK = dS^T·Q.
+template <int DC>
+__global__ __launch_bounds__(256) void qt_attn_bwd_dkv_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DH = DC * 16, LDK = DH + 4, V4 = DH / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int kvn = blockIdx.x / p.H, hd = blockIdx.x - kvn * p.H;
+    const int Lq = p.Lq, Lk = p.Lk;
+    const int k0 = (blockIdx.y * 4 + wave) * 16;
+    const bool wave_on = k0 < Lk;
+    const int key = k0 + c;
+    const bool kok = wave_on && key < Lk;
+    float* Qs = lds;
+    float* Gs = Qs + SKC * LDK;
+    float4 kf[DC], vf[DC];
+#pragma unroll
+    for (int ch = 0; ch < DC; ++ch) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
+        if (kok) {
+            const long row = (long)kvn * p.kv_is + key;
+            t = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + ch * 16 + g * 4);
+            u = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + ch * 16 + g * 4);
+        }
+        kf[ch] = t; vf[ch] = u;
+    }
+    floatx4v av[DC], ak[DC];
+#pragma unroll
+    for (int dt = 0; dt < DC; ++dt) { av[dt] = floatx4v{0.f, 0.f, 0.f, 0.f}; ak[dt] = av[dt]; }
+    int first = (kvn - p.kv_shift) % p.n_kv;
+    if (first < 0) first += p.n_kv;
+    const int reps = p.n_items / p.n_kv;
+    for (int rep = 0; rep < reps; ++rep) {
+        const int n = first + rep * p.n_kv;
+        const long stat0 = ((long)n * p.H + hd) * Lq;
+        for (int qc0 = 0; qc0 < Lq; qc0 += SKC) {
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < SKC * V4; idx += 256) {
+                const int qi = idx / V4, c4 = idx - qi * V4;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
+                if (qc0 + qi < Lq) {
+                    t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)(qc0 + qi) * p.q_rs) * p.ldq + hd * DH + c4 * 4);
+                    u = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)(qc0 + qi) * p.do_rs) * p.lddo + hd * DH + c4 * 4);
+                }
+                *reinterpret_cast<float4*>(Qs + qi * LDK + c4 * 4) = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
+                *reinterpret_cast<float4*>(Gs + qi * LDK + c4 * 4) = u;
+            }
+            __syncthreads();
+            if (!wave_on) continue;
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                if (qc0 + qt * 16 >= Lq) continue;
+                floatx4v a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < DC; ++ch) {
+                    const float4 qv = *reinterpret_cast<const float4*>(Qs + (qt * 16 + c) * LDK + ch * 16 + g * 4);
+                    const float4 gv = *reinterpret_cast<const float4*>(Gs + (qt * 16 + c) * LDK + ch * 16 + g * 4);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kf[ch].x, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.x, vf[ch].x, a2, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kf[ch].y, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.y, vf[ch].y, a2, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kf[ch].z, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.z, vf[ch].z, a2, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kf[ch].w, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gv.w, vf[ch].w, a2, 0, 0, 0);
+                }
+                floatx4v pd, ds;                                    // element j <-> query qc0 + qt*16 + 4g + j, column = key (lane c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qq = qc0 + qt * 16 + g * 4 + j;
+                    const bool ok = kok && qq < Lq;
+                    const float lse = ok ? p.lse[stat0 + qq] : 0.f;
+                    const float dl = ok ? p.delta[stat0 + qq] : 0.f;
+                    const float pr = ok ? __expf(a1[j] - lse) : 0.f;
+                    const float mult = (p.drop_p > 0.f && ok)
+                        ? qt_drop_mult(p.seed, (unsigned long long)(stat0 + qq) * (unsigned long long)Lk + key, p.drop_p, p.inv_keep) : 1.0f;
+                    pd[j] = pr * mult;
+                    ds[j] = pr * (a2[j] * mult - dl);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* grow = Gs + (qt * 16 + g * 4 + j) * LDK + c;
+                    const float* qrow = Qs + (qt * 16 + g * 4 + j) * LDK + c;
+#pragma unroll
+                    for (int dt = 0; dt < DC; ++dt) {
+                        av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[j], grow[dt * 16], av[dt], 0, 0, 0);
+                        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[j], qrow[dt * 16], ak[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ko = k0 + g * 4 + j;
+        if (ko < Lk) {
+            const long row = (long)kvn * p.kv_is + ko;
+            float* dkp = p.dk + row * p.lddk + hd * DH + c;
+            float* dvp = p.dv + row * p.lddv + hd * DH + c;
+#pragma unroll
+            for (int dt = 0; dt < DC; ++dt) { dkp[dt * 16] = ak[dt][j]; dvp[dt * 16] = av[dt][j]; }
+        }
+    }
+}
+
+static bool attn_stream_ok(const AttnArgs& a, bool bwd) {
+    if (a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 48 || a.dh == 80 || a.dh == 112) return false;
+    const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
+    if (!al || !a.lse) return false;
+    if (bwd && !(qt_aligned16(a.d_o) && a.lddo % 4 == 0 && a.o_fwd && qt_aligned16(a.o_fwd) && a.delta && a.n_items % a.n_kv == 0)) return false;
+    return true;
+}
+template <int DC>
+static int launch_fwd_stream(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = sizeof(float) * 2 * SKC * (DC * 16 + 4);
+    auto kern = qt_attn_fwd_stream_kernel<DC>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)a.n_items * a.H), (unsigned)(((a.Lq + 15) / 16 + 3) / 4)), dim3(256), lds, st, a);
+    return 0;
+}
+template <int DC>
+static int launch_bwd_stream(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = sizeof(float) * 2 * SKC * (DC * 16 + 4);
+    auto k1 = qt_attn_bwd_dq_kernel<DC>;
+    auto k2 = qt_attn_bwd_dkv_kernel<DC>;
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(k1, dim3((unsigned)((long)a.n_items * a.H), (unsigned)(((a.Lq + 15) / 16 + 3) / 4)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k2, dim3((unsigned)((long)a.n_kv * a.H), (unsigned)(((a.Lk + 15) / 16 + 3) / 4)), dim3(256), lds, st, a);
+    return 0;
+}
+#define QT_ATTN_STREAM_DISPATCH(fn, a, st, rc)                    \
+    do {                                                          \
+        const int dc_ = (a).dh / 16;                              \
+        rc = -1;                                                  \
+        if (dc_ == 2) rc = fn<2>(a, st); else if (dc_ == 4) rc = fn<4>(a, st); \
+        else if (dc_ == 6) rc = fn<6>(a, st); else if (dc_ == 8) rc = fn<8>(a, st); \
+    } while (0)
+
 static bool attn_mfma_ok(const AttnArgs& a, bool bwd) {
     if (a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 80 || a.dh == 48 || a.dh == 112) return false;
-    if (a.Lk > 128) return false;
-    if (bwd && (a.Lq > 64 || a.n_items % a.n_kv != 0)) return false;
+    if (a.Lk > 128 || a.Lq > 64) return false;       // longer: streaming kernels (fwd too, so that lse exists for their bwd)
+    if (bwd && a.n_items % a.n_kv != 0) return false;
     const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
     if (!al) return false;
     if (bwd && !(qt_aligned16(a.d_o) && a.lddo % 4 == 0)) return false;
@@ -579,7 +953,7 @@ extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, lo
                            const float* k, long ldk, const float* v, long ldv, long kv_is,
                            float* o, long ldo, long o_is, long o_rs,
                            int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
-                           float scale, float drop_p, unsigned long long seed) {
+                           float scale, float drop_p, unsigned long long seed, float* lse) {
     QT_CHECK_ARG(q && k && v && o, "qt_attn_fwd: null pointer");
     QT_CHECK_ARG(n_items > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dh > 0, "qt_attn_fwd: bad sizes");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_attn_fwd: drop_p=%f", drop_p);
@@ -587,17 +961,22 @@ extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, lo
     a.q = q; a.ldq = ldq; a.q_is = q_is; a.q_rs = q_rs; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.kv_is = kv_is;
     a.o = o; a.ldo = ldo; a.o_is = o_is; a.o_rs = o_rs;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
-    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.lse = lse;
     if (attn_mfma_ok(a, false)) {
         int rc;
         QT_ATTN_DISPATCH(launch_fwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return QT_OK; }
     }
+    if (attn_stream_ok(a, false)) {                                  // long sequences: stream K/V with an online softmax
+        int rc;
+        QT_ATTN_STREAM_DISPATCH(launch_fwd_stream, a, (hipStream_t)stream, rc);
+        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(stream)"); return QT_OK; }
+    }
     const int dp = dh + 1;
     const size_t lds = sizeof(float) * ((size_t)Lq * dp + (size_t)Lk * dp + (size_t)Lk * dh + (size_t)Lq * (Lk + 1));
     if (lds > 160 * 1024)
         QT_FAIL(QT_ERR_UNSUPPORTED, "qt_attn_fwd: Lq=%d Lk=%d dh=%d needs %zu B of LDS (>160 KiB); "
-                "long-sequence tiling is not built yet", Lq, Lk, dh, lds);
+                "the streaming kernels need d_h in {32,64,96,128}, 16-byte aligned rows and an lse buffer", Lq, Lk, dh, lds);
     hipStream_t st = (hipStream_t)stream;
     const long blocks = (long)n_items * H;
     QT_CHECK_ARG(blocks < (1L << 31), "qt_attn_fwd: grid too large");
@@ -618,7 +997,8 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
                            float* dq, long lddq, long dq_is, long dq_rs,
                            float* dk, long lddk, float* dv, long lddv,
                            int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
-                           float scale, float drop_p, unsigned long long seed) {
+                           float scale, float drop_p, unsigned long long seed,
+                           const float* o_fwd, const float* lse, float* delta_ws) {
     QT_CHECK_ARG(q && k && v && d_o && dq && dk && dv, "qt_attn_bwd: null pointer");
     QT_CHECK_ARG(n_items > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dh > 0, "qt_attn_bwd: bad sizes");
     QT_CHECK_ARG(n_kv <= n_items, "qt_attn_bwd: n_kv=%d > n_items=%d leaves kv rows without a gradient", n_kv, n_items);
@@ -628,16 +1008,22 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
     a.dq = dq; a.lddq = lddq; a.dq_is = dq_is; a.dq_rs = dq_rs; a.dk = dk; a.lddk = lddk; a.dv = dv; a.lddv = lddv;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
     a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    a.o_fwd = o_fwd; a.lse = (float*)lse; a.delta = delta_ws;
     if (attn_mfma_ok(a, true) && qt_aligned16(dq) && qt_aligned16(dk) && qt_aligned16(dv)) {
         int rc;
         QT_ATTN_DISPATCH(launch_bwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(mfma)"); return QT_OK; }
     }
+    if (attn_stream_ok(a, true)) {
+        int rc;
+        QT_ATTN_STREAM_DISPATCH(launch_bwd_stream, a, (hipStream_t)stream, rc);
+        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(stream)"); return QT_OK; }
+    }
     const int dp = dh + 1;
     const size_t lds = sizeof(float) * (2 * (size_t)Lq * dp + 2 * (size_t)Lk * dp + 2 * (size_t)Lq * (Lk + 1));
     if (lds > 160 * 1024)
         QT_FAIL(QT_ERR_UNSUPPORTED, "qt_attn_bwd: Lq=%d Lk=%d dh=%d needs %zu B of LDS (>160 KiB); "
-                "long-sequence tiling is not built yet", Lq, Lk, dh, lds);
+                "the streaming kernels need d_h in {32,64,96,128}, 16-byte aligned rows and an lse buffer", Lq, Lk, dh, lds);
     hipStream_t st = (hipStream_t)stream;
     const long blocks = (long)n_kv * H;
     QT_CHECK_ARG(blocks < (1L << 31), "qt_attn_bwd: grid too large");

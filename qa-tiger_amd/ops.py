@@ -271,9 +271,10 @@ class AttnSpec:
         self.scale = 1.0 / math.sqrt(self.dh)
 
 
-def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int) -> Tensor:
+def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int):
     _dev(qbuf, kvbuf)
     o = torch.empty((s.o_rows, s.E), device=qbuf.device, dtype=torch.float32)
+    lse = torch.empty((s.n_items * s.H * s.Lq,), device=qbuf.device, dtype=torch.float32)   # used by the streaming path
     f4 = 4
     nbytes = 4.0 * s.E * (2 * s.n_items * s.Lq + 2 * s.n_kv * s.Lk)
     rc = _launch('attn_fwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_fwd(
@@ -281,9 +282,9 @@ def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int
         C.c_void_p(kvbuf.data_ptr() + s.k_col * f4), _ld(kvbuf),
         C.c_void_p(kvbuf.data_ptr() + s.v_col * f4), _ld(kvbuf), s.Lk,
         _ptr(o), s.E, s.o_is, s.o_rs,
-        s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed)))
+        s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed), _ptr(lse)))
     _lib.check(rc, 'qt_attn_fwd')
-    return o
+    return o, lse
 
 
 class AttentionFn(torch.autograd.Function):
@@ -294,14 +295,14 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float, seed: int):
         qb = as2d(qbuf)
         kb = qb if kvbuf is None else as2d(kvbuf)
-        o = _attn_fwd(qb, kb, spec, drop_p, seed)
-        ctx.save_for_backward(qb, kb if kvbuf is not None else None)
+        o, lse = _attn_fwd(qb, kb, spec, drop_p, seed)
+        ctx.save_for_backward(qb, kb if kvbuf is not None else None, o, lse)
         ctx.cfg = (spec, drop_p, seed, qbuf.shape, None if kvbuf is None else kvbuf.shape)
         return o
 
     @staticmethod
     def backward(ctx, d_o: Tensor):
-        qb, kb_saved = ctx.saved_tensors
+        qb, kb_saved, o_fwd, lse = ctx.saved_tensors
         s, drop_p, seed, qshape, kvshape = ctx.cfg
         packed = kb_saved is None
         kb = qb if packed else kb_saved
@@ -311,6 +312,7 @@ class AttentionFn(torch.autograd.Function):
         dqb = torch.zeros_like(qb) if (not packed and qb.shape[1] != s.E) else torch.empty_like(qb, memory_format=torch.contiguous_format)
         dkb = dqb if packed else torch.empty_like(kb, memory_format=torch.contiguous_format)
         f4 = 4
+        delta_ws = torch.empty_like(lse)
         nbytes = 4.0 * s.E * (3 * s.n_items * s.Lq + 4 * s.n_kv * s.Lk)      # q, dO, dq + k, v, dk, dv
         rc = _launch('attn_bwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_bwd(
             _stream(), C.c_void_p(qb.data_ptr() + s.q_col * f4), _ld(qb), s.q_is, s.q_rs,
@@ -320,7 +322,8 @@ class AttentionFn(torch.autograd.Function):
             C.c_void_p(dqb.data_ptr() + s.q_col * f4), _ld(dqb), s.q_is, s.q_rs,
             C.c_void_p(dkb.data_ptr() + s.k_col * f4), _ld(dkb),
             C.c_void_p(dkb.data_ptr() + s.v_col * f4), _ld(dkb),
-            s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed)))
+            s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed),
+            _ptr(o_fwd), _ptr(lse), _ptr(delta_ws)))
         _lib.check(rc, 'qt_attn_bwd')
         return dqb.reshape(qshape), (None if packed else dkb.reshape(kvshape)), None, None, None
 

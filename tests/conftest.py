@@ -53,6 +53,7 @@ GOLDEN_CONFIGS = {
     'toy_kk': ('CONFIG_TOY_KK', None, 11),
     'config1': ('CONFIG_1', None, 713),
     'config2_b8': ('CONFIG_2', {'B': 8}, 713),
+    'config4_b2': ('CONFIG_4', {'B': 2}, 713),      # long-video stress shape: T=300, D=1024, K=16
 }
 
 

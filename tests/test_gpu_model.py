@@ -164,6 +164,28 @@ def test_config2_full_b256_forward_vs_oracle(qt, synth, oracle):
     print(f'B=256 rel logit err {e:.2e}, min router gaps {gaps}')
 
 
+def test_config4_long_video_b8_vs_oracle(qt, synth, oracle):
+    """BASELINE config 4 shape (T=300, D=1024, K=16; streaming attention, d_h=128) at B=8: logits, arg-max, top-k order."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_4.asdict(), 'B': 8})
+    _oracle_vs_hip(qt, synth, oracle, cfg, 713, with_grads=False)
+
+
+def test_config4_full_size_b128_invariances(qt, synth):
+    """Config 4 at its full size (B=128, T=300, D=1024, K=16): finite, deterministic to rounding, and
+    invariant to patch-token / word permutations (no positional terms, no masks)."""
+    cfg = synth.CONFIG_4
+    model = build(qt, synth, cfg, 713)
+    inp = qt.synth.fast_device_inputs(cfg, DEV, seed=9)
+    with torch.no_grad():
+        base = model(inp)['out']
+        pp = torch.randperm(cfg.P, device=DEV)
+        wp = torch.randperm(cfg.L, device=DEV)
+        out_p = model({**inp, 'patch': inp['patch'][:, :, pp], 'words_feat': inp['words_feat'][:, wp]})['out']
+    scale = float(base.abs().max())
+    assert torch.isfinite(base).all() and base.shape == (cfg.B, 42)
+    assert float((out_p - base).abs().max()) / scale < 1e-4
+
+
 def test_full_size_invariances(qt, synth):
     """Size-independent properties at B=256: the path has no positional term on patch
     tokens or words and no masks, so permuting them must not

@@ -240,8 +240,67 @@ def test_attention_dropout_statistics(ops):
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
 
 
-def test_attention_too_long_fails_loudly(ops, qt):
-    E, H, L = 1024, 8, 300
+@pytest.mark.parametrize('N,nkv,shift,Lq,Lk,E', [
+    (3, 3, 0, 300, 300, 1024),   # BASELINE config 4: T=300, d_h=128 self-attention
+    (4, 4, 2, 300, 300, 512),    # cross on the stacked batch, d_h=64
+    (2, 2, 0, 130, 130, 768),    # just past the resident limits, ragged last chunk/tile
+    (2, 2, 0, 100, 100, 256),    # d_h=32
+])
+def test_attention_streaming_packed(ops, N, nkv, shift, Lq, Lk, E):
+    """Key-chunked online-softmax forward and the two-kernel backward (long sequences)."""
+    H = 8
+    qkv = rnd(N * Lq, 3 * E, seed=31).requires_grad_(True)
+    spec = ops.AttnSpec(N, nkv, shift, H, Lq, Lk, E, 0, E, 2 * E)
+    o = ops.attention(qkv, None, spec)
+    go = rnd(N * Lq, E, seed=32)
+    o.backward(go)
+    x = qkv.detach().double().requires_grad_(True)
+    q, k, v = [x[:, i * E:(i + 1) * E].reshape(N, Lq, E) for i in range(3)]
+    idx = (torch.arange(N, device=DEV) + shift) % nkv
+    ref = ref_attention(q, k[idx], v[idx], H).reshape(N * Lq, E)
+    ref.backward(go.double())
+    assert rel(o, ref) < 2e-5
+    assert rel(qkv.grad, x.grad) < 5e-5
+
+
+@pytest.mark.parametrize('N,nkv,Lq,Lk,E', [(6, 3, 300, 77, 1024), (5, 5, 1, 300, 1024), (4, 2, 70, 200, 768)])
+def test_attention_streaming_q_and_kv(ops, N, nkv, Lq, Lk, E):
+    H = 8
+    qb = rnd(N * Lq, E, seed=33).requires_grad_(True)
+    kvb = rnd(nkv * Lk, 2 * E, seed=34).requires_grad_(True)
+    spec = ops.AttnSpec(N, nkv, 0, H, Lq, Lk, E, 0, 0, E)
+    o = ops.attention(qb, kvb, spec)
+    go = rnd(N * Lq, E, seed=35)
+    o.backward(go)
+    qr, kr = qb.detach().double().requires_grad_(True), kvb.detach().double().requires_grad_(True)
+    idx = torch.arange(N, device=DEV) % nkv
+    ref = ref_attention(qr.reshape(N, Lq, E), kr[:, :E].reshape(nkv, Lk, E)[idx], kr[:, E:].reshape(nkv, Lk, E)[idx], H).reshape(N * Lq, E)
+    ref.backward(go.double())
+    assert rel(o, ref) < 2e-5
+    assert rel(qb.grad, qr.grad) < 5e-5 and rel(kvb.grad, kr.grad) < 5e-5
+
+
+def test_attention_streaming_dropout_consistency(ops):
+    """Forward and both backward kernels must regenerate the same mask: <dO, dOut/dV·δV> = <dV, δV>."""
+    N, L, E, H, p = 2, 200, 512, 8, 0.1
+    qkv = rnd(N * L, 3 * E, seed=36)
+    spec = ops.AttnSpec(N, N, 0, H, L, L, E, 0, E, 2 * E)
+    x = qkv.clone().requires_grad_(True)
+    out = ops.attention(x, None, spec, p, 7)
+    assert torch.equal(out, ops.attention(qkv, None, spec, p, 7))
+    go = rnd(N * L, E, seed=37)
+    out.backward(go)
+    for cols in (slice(2 * E, 3 * E), slice(0, E), slice(E, 2 * E)):            # V (linear), then Q and K (first order)
+        xv = qkv.clone()
+        dlt = 1e-3 * rnd(N * L, E, seed=38)
+        xv[:, cols] += dlt
+        lhs = float(((ops.attention(xv, None, spec, p, 7) - out.detach()) * go).sum())
+        rhs = float((x.grad[:, cols] * dlt).sum())
+        assert abs(lhs - rhs) < 2e-2 * max(1e-3, abs(lhs)) + 1e-4
+
+
+def test_attention_unsupported_shape_fails_loudly(ops, qt):
+    E, H, L = 192, 8, 300                                  # d_h = 24: neither MFMA path applies and the generic kernel needs > 160 KiB
     qkv = torch.zeros(L, 3 * E, device=DEV)
     with pytest.raises(qt.QTError, match='LDS'):
         ops.attention(qkv, None, ops.AttnSpec(1, 1, 0, H, L, L, E, 0, E, 2 * E))

@@ -193,7 +193,8 @@ def main():
     jobs = [('toy', synth.CONFIG_TOY, 713, 'all'),
             ('toy_kk', synth.CONFIG_TOY_KK, 11, 'all'),
             ('config1', synth.CONFIG_1, 713, 'summary'),
-            ('config2_b8', synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 8}), 713, 'summary')]
+            ('config2_b8', synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 8}), 713, 'summary'),
+            ('config4_b2', synth.PathConfig(**{**synth.CONFIG_4.asdict(), 'B': 2}), 713, 'summary')]
     for name, cfg, seed, kg in jobs:
         rec = run_reference(net, cfg, seed, keep_grads=kg)
         path = os.path.join(OUT, f'{name}.npz')
