@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--strong', action='store_true', help='shard a GLOBAL batch of --batch over the ranks instead')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16, help='batch of the bounded CPU-baseline sample')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra instrumented steps for the roofline (after the timed region)')
     return ap.parse_args()
 
@@ -87,11 +88,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)                             # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.backend == 'nccl':
+            dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.backend, init_method='env://')
     qt = importlib.import_module('qa-tiger_amd')
     synth, ops = qt.synth, qt.ops
 
@@ -192,7 +198,7 @@ def main():
                                    'CLIP/VGGish/ToMe-shaped features, reference initialisers',
                        'per_gpu_batch': per_gpu, 'global_batch': per_gpu * world, 'T': cfg.T, 'D': cfg.D, 'video_dim': cfg.Dv,
                        'audio_dim': cfg.Da, 'patch_dim': cfg.Dp, 'P': cfg.P, 'L': cfg.L, 'experts': cfg.K, 'topK': cfg.k,
-                       'parallelism': f'dp{world}'},
+                       'parallelism': f'dp{world}', 'backend': ('rccl' if args.backend == 'nccl' else args.backend) if world > 1 else None},
             'fwd_only': {'value': round(fwd_value, 2), 'unit': 'QA-pairs/s', 'mode': 'eval, no_grad', 'target': 10000,
                          'algorithmic_tflops': round(fwd_value * GFLOP_FWD * 1e9 / 1e12 / world, 1)},
             'loss': round(float(loss), 5),
