@@ -12,6 +12,10 @@ shapes = [  # (M, N, K, ta, tb, label)
     (768, 768, 30720, 1, 0, 'AVQ out-proj dW (TN)'),
     (3072, 768, 30720, 1, 0, 'expert W1 dW (TN)'),
     (256, 768, 768, 0, 1, 'quest-side small (NT)'),
+    (30720, 2304, 768, 0, 1, 'AVQ in-proj fwd (NT)'),
+    (30720, 768, 768, 0, 0, 'AVQ out-proj dX (NN)'),
+    (15360, 3072, 768, 0, 1, 'expert W1 fwd (NT)'),
+    (19712, 1536, 768, 0, 1, 'words kv fwd (NT)'),
 ]
 modes = sys.argv[1:] or ['fp32', 'f16x3', 'bf16x3']
 g = torch.Generator(device='cuda').manual_seed(0)
