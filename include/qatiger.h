@@ -37,12 +37,15 @@ const char* qt_last_error(void);
  * epilogue order: +bias[n], +add_src[m,n], relu, mask (mask_src[m,n]>0 ? v*mask_scale : 0),
  * dropout(drop_p, drop_seed, element index m*N+n), accumulate (C += v).
  * split_k: 0 = auto, 1 = off, >1 = K split over workgroups with fp32 atomics
- * (linear epilogues only). */
+ * (linear epilogues only).
+ * batch > 1: `batch` independent problems of the same shape in one launch (one per attention head);
+ * problem z uses A + z*a_bs, B + z*b_bs, C + z*c_bs (element strides); no bias/residual/mask then. */
 int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
                 const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                 const float* bias, const float* add_src, long ld_add, int relu,
                 const float* mask_src, long ld_mask, float mask_scale,
-                float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
+                float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
+                int batch, long a_bs, long b_bs, long c_bs);
 
 /* Same contract as qt_gemm_f32, computed with three 16-bit MFMAs per product on operands split
  * on the fly into hi+lo parts (half_type 0: fp16 parts, ~fp32-accurate, operands must be inside
@@ -55,7 +58,8 @@ int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N
                const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                const float* bias, const float* add_src, long ld_add, int relu,
                const float* mask_src, long ld_mask, float mask_scale,
-               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum);
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
+               int batch, long a_bs, long b_bs, long c_bs);
 
 /* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
  * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward
@@ -79,6 +83,20 @@ int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
                 int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
                 float scale, float drop_p, unsigned long long seed,
                 const float* o_fwd, const float* lse, float* delta_ws);
+
+/* Few-query attention with the K/V projections folded away (modules.py:562 TempMoE.qst_attn, Lq=1;
+ * modules.py:692-698 PatchSelecter.crs_attn, Lq=2).  u = W_k,h^T q'_h per (query, head) is the "query",
+ * the raw rows x (dimension D) are keys AND values:  s_p = scale*u.x_p, a = softmax_p(s) (+dropout),
+ * ctx = sum_p a_p x_p, asum = sum_p a_p, lse = log-sum-exp.  Element (item n, query i, head h) of
+ * u / ctx is row ((n*u_is + i*u_rs)*H + h) of a [*, D] matrix; lse / asum are indexed by that row.
+ * The caller applies W_k / W_v with head-batched qt_gemm_* launches. */
+int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
+                 int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
+                 float* ctx, float* lse, float* asum);
+int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
+                 const float* ctx, const float* lse, const float* asum, const float* dctx, const float* dasum,
+                 int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
+                 float* du, float* dx);
 
 /* y = LayerNorm(sum_i sx[i] * dropout_i(x[i])) (+ optional ReLU on y); n_add <= 4.
  * Replaces modules.py:223-229, 233-235, 344-346, 603, 612, 713-716.

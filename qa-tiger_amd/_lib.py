@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
-SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'norm.hip', 'moe.hip', 'misc.hip']
+SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip']
 GFX = 'gfx950'
 
 
@@ -46,8 +46,10 @@ _i, _l, _f, _u64 = C.c_int, C.c_long, C.c_float, C.c_ulonglong
 
 # name -> argtypes; every function returns int (0 = ok) except the two noted
 SIGNATURES = {
-    'qt_gemm_f32': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
-    'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p],
+    'qt_gemm_f32': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _i, _l, _l, _l],
+    'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _i, _l, _l, _l],
+    'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
+    'qt_xattn_bwd': [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p],
     'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
                     _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],

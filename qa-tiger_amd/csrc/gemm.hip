@@ -44,6 +44,7 @@ struct GemmArgs {
     int split_k;                       // >1: K split over gridDim.y, atomically added into C
     int k_per_split;                   // multiple of BK
     int tiles_n;
+    long a_bs, b_bs, c_bs;             // strides between the gridDim.z problems of a batched launch
 };
 
 template <int TM, int TN, bool TA, bool TB, int VEC>
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void qt_gemm_f32_kernel(GemmArgs p) {
     constexpr int A_TILE = TA ? BK * BM : BM * LDK;
     constexpr int B_TILE = TB ? BN * LDK : BK * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    p.A += (long)blockIdx.z * p.a_bs; p.B += (long)blockIdx.z * p.b_bs; p.C += (long)blockIdx.z * p.c_bs;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -250,22 +252,27 @@ extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, i
                            const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                            const float* bias, const float* add_src, long ld_add, int relu,
                            const float* mask_src, long ld_mask, float mask_scale,
-                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
+                           int batch, long a_bs, long b_bs, long c_bs) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0, "qt_gemm_f32: empty problem M=%d N=%d K=%d", M, N, K);
     QT_CHECK_ARG(A && B && C, "qt_gemm_f32: null operand");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_f32: drop_p=%f", drop_p);
     QT_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                  "qt_gemm_f32: leading dimension smaller than row (lda=%ld ldb=%ld ldc=%ld)", lda, ldb, ldc);
+    if (batch < 1) batch = 1;
+    QT_CHECK_ARG(batch == 1 || (!bias && !add_src && !mask_src), "qt_gemm_f32: batched launches take no bias/residual/mask");
+    QT_CHECK_ARG(batch <= 65535, "qt_gemm_f32: batch too large");
     hipStream_t st = (hipStream_t)stream;
     GemmArgs a;
+    a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
 
     // 16-byte vector staging needs aligned rows; otherwise the scalar-load build of the same kernel
-    const bool vecA = qt_aligned16(A) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0);
-    const bool vecB = qt_aligned16(B) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0);
+    const bool vecA = qt_aligned16(A) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (batch == 1 || a_bs % 4 == 0);
+    const bool vecB = qt_aligned16(B) && (ldb % 4 == 0) && ((transB ? K : N) % 4 == 0) && (batch == 1 || b_bs % 4 == 0);
     const int vec = (vecA && vecB) ? 4 : 1;
 
     const bool small = ((long)M * N <= 512L * 768L) || M <= 64 || N <= 64;
@@ -290,11 +297,13 @@ extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, i
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
     if (split_k > 1 && !accumulate) {   // partial sums are atomically added into a zeroed C
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
-        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_f32: memset: %s", hipGetErrorString(e));
+        for (int z = 0; z < batch; ++z) {
+            hipError_t e = hipMemset2DAsync(C + (long)z * c_bs, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+            if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_f32: memset: %s", hipGetErrorString(e));
+        }
     }
     QT_CHECK_ARG(tiles < (1L << 31), "qt_gemm_f32: grid too large");
-    dim3 grid((unsigned)tiles, (unsigned)split_k);
+    dim3 grid((unsigned)tiles, (unsigned)split_k, (unsigned)batch);
     if (small) { if (vec == 4) launch_cfg<1, 1, 4>(a, transA, transB, grid, st); else launch_cfg<1, 1, 1>(a, transA, transB, grid, st); }
     else       { if (vec == 4) launch_cfg<2, 2, 4>(a, transA, transB, grid, st); else launch_cfg<2, 2, 1>(a, transA, transB, grid, st); }
     QT_CHECK_LAUNCH("qt_gemm_f32");

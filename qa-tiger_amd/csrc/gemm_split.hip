@@ -50,6 +50,7 @@ struct GemmArgs {          // identical to gemm.hip
     int k_per_split;
     int tiles_n;
     int tiles_m;
+    long a_bs, b_bs, c_bs;    // element strides between the gridDim.z problems of a batched launch (heads)
     float* a_colsum;          // transA only: a_colsum[m] += sum_k A[k,m]  (bias gradient riding on the dW GEMM)
 };
 
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     static_assert(LA * 4 == BM * SBK / NT && LB * 4 == BN * SBK / NT, "tile/threads mismatch");
     static_assert(NT % BM == 0 && NT % BN == 0, "K-slow staging needs NT multiple of the tile edge");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    p.A += (long)blockIdx.z * p.a_bs; p.B += (long)blockIdx.z * p.b_bs; p.C += (long)blockIdx.z * p.c_bs;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave - wm * NWN;
@@ -396,15 +398,20 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                           const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
-                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum) {
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
+                          int batch, long a_bs, long b_bs, long c_bs) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_x3: bad problem");
     QT_CHECK_ARG(!a_colsum || transA, "qt_gemm_x3: a_colsum needs transA (A given as [K,M])");
+    if (batch < 1) batch = 1;
+    QT_CHECK_ARG(batch == 1 || (!bias && !add_src && !mask_src && !a_colsum), "qt_gemm_x3: batched launches take no bias/residual/mask/colsum");
+    QT_CHECK_ARG(batch <= 65535, "qt_gemm_x3: batch too large");
     const int force = half_type >> 4;
     half_type &= 15;
     QT_CHECK_ARG(half_type == 0 || half_type == 1, "qt_gemm_x3: half_type must be 0 (fp16) or 1 (bf16)");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_x3: drop_p=%f", drop_p);
     QT_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "qt_gemm_x3: leading dimension too small");
     // K-contiguous operands are staged with 16-byte loads
+    if (batch > 1 && ((!transA && a_bs % 4) || (transB && b_bs % 4))) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: batch stride breaks 16-byte alignment");
     if (!transA && !(qt_aligned16(A) && lda % 4 == 0 && K % 4 == 0)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: A not 16-byte aligned");
     if (transB && !(qt_aligned16(B) && ldb % 4 == 0 && K % 4 == 0)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: B not 16-byte aligned");
     {   // per-thread offsets are 32-bit byte offsets from a wave-uniform base
@@ -419,7 +426,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
-    a.a_colsum = a_colsum;
+    a.a_colsum = a_colsum; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
 
@@ -440,13 +447,13 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         // rounds of resident workgroups x (BK steps per workgroup + a fixed prologue/epilogue/atomics
         // overhead worth `ovh` steps); minimise it.
         split_k = 1;
-        if (plain_epilogue && tiles < 2 * slots && K >= 16 * SBK) {
+        if (plain_epilogue && tiles * batch < 2 * slots && K >= 16 * SBK) {
             const long ovh = big ? 16 : 8;
             long maxs = K / (8 * SBK);
             if (maxs > 64) maxs = 64;
             long best = -1;
             for (long s = 1; s <= maxs; ++s) {
-                const long rounds = (tiles * s + slots - 1) / slots;
+                const long rounds = (tiles * s * batch + slots - 1) / slots;
                 const long ksteps = ((K + s - 1) / s + SBK - 1) / SBK;
                 const long cost = rounds * (ksteps + ovh);
                 if (best < 0 || cost < best) { best = cost; split_k = (int)s; }
@@ -458,15 +465,17 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
     if (split_k > 1 && !accumulate) {
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
-        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
+        for (int z = 0; z < batch; ++z) {
+            hipError_t e = hipMemset2DAsync(C + (long)z * c_bs, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+            if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
+        }
     }
     if (a_colsum) {
         hipError_t e = hipMemsetAsync(a_colsum, 0, sizeof(float) * (size_t)M, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
     }
     QT_CHECK_ARG(tiles < (1L << 31), "qt_gemm_x3: grid too large");
-    dim3 grid((unsigned)tiles, (unsigned)split_k);
+    dim3 grid((unsigned)tiles, (unsigned)split_k, (unsigned)batch);
     if (big) { if (half_type == 0) launch_x3<4, 2, 2, 4, 1, 0>(a, transA, transB, grid, st); else launch_x3<4, 2, 2, 4, 1, 1>(a, transA, transB, grid, st); }
     else     { if (half_type == 0) launch_x3<2, 2, 2, 2, 2, 0>(a, transA, transB, grid, st); else launch_x3<2, 2, 2, 2, 2, 1>(a, transA, transB, grid, st); }
     QT_CHECK_LAUNCH("qt_gemm_x3");

@@ -1,0 +1,353 @@
+// Few-query attention with the K/V projections folded away (fp32), forward and backward.
+//
+// For an attention whose queries are few (Lq = 1: TempMoE.qst_attn, reference
+// src/models/modules.py:562; Lq = 2: PatchSelecter.crs_attn, modules.py:692-698) the
+// packed K/V in-projection of every key row is wasted work.  With x_p the raw key rows
+// (dimension D) and q'_h the projected query of head h:
+//     score_h[p] = (W_k,h^T q'_h) · x_p + q'_h·b_k,h        (the bias term is constant in p: softmax drops it)
+//     out_h      = W_v,h ( Σ_p a_h[p] x_p ) + b_v,h Σ_p a_h[p]
+// (SURVEY.md §7 "Legitimate algebraic savings", Appendix A step 1).  The host computes
+// u_h = W_k,h^T q'_h with a head-batched GEMM; THIS kernel does, per item and per (query, head):
+//     s_p = scale · u · x_p,   a = softmax_p(s) (+ dropout),   ctx = Σ_p a_p x_p,   asum = Σ_p a_p
+// and the host applies W_v,h with a second head-batched GEMM.  At the primary config this
+// removes the 215040 x 1536 x 768 GEMM (17 % of all GEMM FLOPs) and its two backward GEMMs.
+//
+// Layout: U and CTX are [rows, NQH·? ] = element (item n, query i, head h, col c) at
+//   ((n*u_is + i*u_rs) * H + h) * D + c;  X rows of item n are rows n*Lk .. n*Lk+Lk-1 of [*, D].
+// One workgroup per item.  A wave owns QB (query, head) vectors at a time, each lane D/64 columns;
+// rows of X are staged chunk-wise in LDS (coalesced 16-byte loads), scores use an online softmax,
+// dot products reduce with wavefront shuffles.  HBM/L2-bound.
+#include "qt_common.h"
+
+#define XA_MAXV 4      // float4 per lane: D <= 1024
+
+struct XAttnArgs {
+    const float* u; const float* x; float* ctx; float* lse; float* asum;
+    long u_is, u_rs; int n_items, H, Lq, Lk, D;
+    int bch, gq;             // backward: rows per staged chunk, (query, head) slots held in LDS
+    float scale, drop_p, inv_keep; unsigned long long seed;
+    // backward
+    const float* dctx; const float* dasum; const float* ctx_in;
+    float* du; float* dx;
+};
+
+__device__ inline float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// Rows of X are staged into LDS in chunks by the whole workgroup (all loads of a chunk in flight
+// at once: a first version that streamed one row at a time per wave was bound by 14 serialised
+// load latencies per item), then every wave reads the chunk for its own (query, head) vectors.
+// Workgroup = 8 waves x 2 vectors (16 (query, head) vectors per pass = PatchSelecter's 2 x 8).
+#define XA_FCH 16      // rows per chunk, forward
+#define XA_BCH 8       // rows per chunk, backward (a second LDS tile of the same size accumulates dX)
+#define XA_NT 512
+
+// Sum 4 per-lane partials over the wavefront with 7 cross-lane exchanges instead of 24: after the
+// xor-32 and xor-16 steps each 16-lane group owns ONE of the four sums (reduce-scatter), four more
+// butterfly steps finish it, and the totals are read back from lanes 0/16/32/48.
+__device__ inline void xa_reduce4(float (&v)[4], int lane) {
+    const bool hi32 = lane & 32, hi16 = lane & 16;
+    float k0 = hi32 ? v[2] : v[0], k1 = hi32 ? v[3] : v[1];
+    const float s0 = hi32 ? v[0] : v[2], s1 = hi32 ? v[1] : v[3];
+    k0 += __shfl_xor(s0, 32, 64); k1 += __shfl_xor(s1, 32, 64);
+    float b = hi16 ? k1 : k0;
+    const float t = hi16 ? k0 : k1;
+    b += __shfl_xor(t, 16, 64);
+    b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 4, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 1, 64);
+    v[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 0));
+    v[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 16));
+    v[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 32));
+    v[3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 48));
+}
+
+__device__ inline void xa_stage_rows(const float* __restrict__ xbase, float* __restrict__ Xs, int r0, int nrows, int Lk, int D, int nv) {
+    for (int idx = threadIdx.x; idx < nrows * nv; idx += XA_NT) {
+        const int r = idx / nv, c4 = idx - r * nv;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < Lk) v = *reinterpret_cast<const float4*>(xbase + (long)(r0 + r) * D + c4 * 4);
+        *reinterpret_cast<float4*>(Xs + r * D + c4 * 4) = v;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
+    constexpr int QB = 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    const int nv = p.D >> 2, NQ = p.Lq * p.H, D = p.D, Lk = p.Lk;
+    const float* xbase = p.x + (long)n * Lk * D;
+    float* Xs = lds;                                                // [XA_FCH][D]
+    const int ngroups = (NQ + 8 * QB - 1) / (8 * QB);               // same trip count for every wave (barriers inside)
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const int q0 = (grp * 8 + wave) * QB;
+        float4 u[QB][NV], acc[QB][NV];
+        float m[QB], l[QB], ls[QB];
+        long urow[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            const int qq = min(q0 + b, NQ - 1);
+            const int i = qq / p.H, h = qq - i * p.H;
+            urow[b] = (((long)n * p.u_is + (long)i * p.u_rs) * p.H + h);
+            m[b] = -INFINITY; l[b] = 0.f; ls[b] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int c4 = lane + t * 64;
+                u[b][t] = c4 < nv ? *reinterpret_cast<const float4*>(p.u + urow[b] * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[b][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int r0 = 0; r0 < Lk; r0 += XA_FCH) {
+            __syncthreads();
+            xa_stage_rows(xbase, Xs, r0, XA_FCH, Lk, D, nv);
+            __syncthreads();
+            const int rn = min(XA_FCH, Lk - r0);
+            for (int r = 0; r < rn; r += 2) {                       // two rows per step: 4 partials per reduction
+                float4 xv[2][NV];
+                float part[4];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) {
+                        const int c4 = lane + t * 64;
+                        xv[rr][t] = (c4 < nv && r + rr < rn) ? *reinterpret_cast<const float4*>(Xs + (r + rr) * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int t = 0; t < NV; ++t) a += dot4(u[b][t], xv[rr][t]);
+                        part[rr * 2 + b] = a;
+                    }
+                xa_reduce4(part, lane);
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    if (r + rr >= rn) continue;
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) {
+                        const float s = part[rr * 2 + b] * p.scale;
+                        const float mn = fmaxf(m[b], s);
+                        const float alpha = __expf(m[b] - mn);
+                        float e = __expf(s - mn);
+                        m[b] = mn;
+                        l[b] = l[b] * alpha + e;
+                        if (p.drop_p > 0.f) e *= qt_drop_mult(p.seed, (unsigned long long)urow[b] * Lk + (r0 + r + rr), p.drop_p, p.inv_keep);
+                        ls[b] = ls[b] * alpha + e;
+#pragma unroll
+                        for (int t = 0; t < NV; ++t) {
+                            acc[b][t].x = fmaf(e, xv[rr][t].x, acc[b][t].x * alpha); acc[b][t].y = fmaf(e, xv[rr][t].y, acc[b][t].y * alpha);
+                            acc[b][t].z = fmaf(e, xv[rr][t].z, acc[b][t].z * alpha); acc[b][t].w = fmaf(e, xv[rr][t].w, acc[b][t].w * alpha);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            if (q0 + b >= NQ) continue;
+            const float inv = 1.0f / l[b];
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int c4 = lane + t * 64;
+                if (c4 < nv)
+                    *reinterpret_cast<float4*>(p.ctx + urow[b] * D + c4 * 4) =
+                        make_float4(acc[b][t].x * inv, acc[b][t].y * inv, acc[b][t].z * inv, acc[b][t].w * inv);
+            }
+            if (lane == 0) { p.lse[urow[b]] = m[b] + __logf(l[b]); p.asum[urow[b]] = ls[b] * inv; }
+        }
+    }
+}
+
+// Backward.  Phase 1 (wave per pair of (query, head) vectors, rows staged chunk-wise): recompute
+// a_p = exp(s_p - lse), da_p = dctx·x_p + dasum, ds_p = a_p (mult_p da_p - delta) with
+// delta = dctx·ctx + dasum·asum; dU += ds_p x_p in registers; the scalars a_d[q,p], scale·ds[q,p] and the
+// u / dctx rows are parked in LDS.  Phase 2 (wave per key row): dX_p = Σ_q a_d[q,p] dctx_q + scale ds[q,p] u_q
+// from LDS.  (LDS float atomics for dX were tried: 8 waves adding to the same 768 addresses ran 7.6 ms.)
+template <int NV>
+__global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
+    constexpr int QB = 2, GQ = 16;        // (query, head) vectors per pass
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    const int nv = p.D >> 2, NQ = p.Lq * p.H, D = p.D, Lk = p.Lk;
+    const int BCH = p.bch, SL = p.gq;     // host sizes them so that everything fits in 160 KiB
+    float* Xs = lds;                      // [BCH][D]
+    float* Us = Xs + BCH * D;             // [SL][D]
+    float* Gs = Us + SL * D;              // [SL][D]
+    float* Ad = Gs + SL * D;              // [SL][Lk]  dropped probabilities
+    float* Ds = Ad + SL * Lk;             // [SL][Lk]  scale * dS
+    const float* xbase = p.x + (long)n * Lk * D;
+    const int ngroups = (NQ + GQ - 1) / GQ;
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const int ql = wave * QB;                                   // slot inside the pass
+        const int q0 = grp * GQ + ql;
+        float4 u[QB][NV], g[QB][NV], acc[QB][NV];
+        float lse[QB], delta[QB], das[QB];
+        long urow[QB];
+        bool live[QB];
+        __syncthreads();                                            // previous pass finished reading Us/Gs/Ad/Ds
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            live[b] = q0 + b < NQ;
+            const int qq = min(q0 + b, NQ - 1);
+            const int i = qq / p.H, h = qq - i * p.H;
+            urow[b] = (((long)n * p.u_is + (long)i * p.u_rs) * p.H + h);
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int c4 = lane + t * 64;
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                u[b][t] = cv; g[b][t] = cv;
+                if (c4 < nv && live[b]) {
+                    u[b][t] = *reinterpret_cast<const float4*>(p.u + urow[b] * D + c4 * 4);
+                    g[b][t] = *reinterpret_cast<const float4*>(p.dctx + urow[b] * D + c4 * 4);
+                    cv = *reinterpret_cast<const float4*>(p.ctx_in + urow[b] * D + c4 * 4);
+                }
+                if (c4 < nv && ql + b < SL) {                       // idle waves own no LDS slot
+                    *reinterpret_cast<float4*>(Us + (ql + b) * D + c4 * 4) = u[b][t];
+                    *reinterpret_cast<float4*>(Gs + (ql + b) * D + c4 * 4) = g[b][t];
+                }
+                part += dot4(g[b][t], cv);
+                acc[b][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            das[b] = (p.dasum && live[b]) ? p.dasum[urow[b]] : 0.f;
+            delta[b] = qt_wave_sum(part) + das[b] * p.asum[urow[b]];
+            lse[b] = p.lse[urow[b]];
+        }
+        for (int r0 = 0; r0 < Lk; r0 += BCH) {
+            __syncthreads();
+            xa_stage_rows(xbase, Xs, r0, BCH, Lk, D, nv);
+            __syncthreads();
+            const int rn = min(BCH, Lk - r0);
+            for (int r = 0; r < rn; ++r) {
+                float4 xv[NV];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const int c4 = lane + t * 64;
+                    xv[t] = c4 < nv ? *reinterpret_cast<const float4*>(Xs + r * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float part[4];                                      // {s_0, s_1, dctx·x_0, dctx·x_1}
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    float a = 0.f, c = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) { a += dot4(u[b][t], xv[t]); c += dot4(g[b][t], xv[t]); }
+                    part[b] = a; part[2 + b] = c;
+                }
+                xa_reduce4(part, lane);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    const float a = live[b] ? __expf(part[b] * p.scale - lse[b]) : 0.f;
+                    const float mult = p.drop_p > 0.f ? qt_drop_mult(p.seed, (unsigned long long)urow[b] * Lk + (r0 + r), p.drop_p, p.inv_keep) : 1.0f;
+                    const float ds = a * ((part[2 + b] + das[b]) * mult - delta[b]);
+                    if (lane == 0 && ql + b < SL) { Ad[(ql + b) * Lk + r0 + r] = a * mult; Ds[(ql + b) * Lk + r0 + r] = ds * p.scale; }
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) {
+                        acc[b][t].x = fmaf(ds, xv[t].x, acc[b][t].x); acc[b][t].y = fmaf(ds, xv[t].y, acc[b][t].y);
+                        acc[b][t].z = fmaf(ds, xv[t].z, acc[b][t].z); acc[b][t].w = fmaf(ds, xv[t].w, acc[b][t].w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            if (!live[b]) continue;
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int c4 = lane + t * 64;
+                if (c4 < nv)
+                    *reinterpret_cast<float4*>(p.du + urow[b] * D + c4 * 4) =
+                        make_float4(acc[b][t].x * p.scale, acc[b][t].y * p.scale, acc[b][t].z * p.scale, acc[b][t].w * p.scale);
+            }
+        }
+        __syncthreads();                                            // Ad / Ds / Us / Gs of this pass complete
+        const int nq = min(GQ, NQ - grp * GQ);
+        for (int r = wave; r < Lk; r += XA_NT / 64) {
+            float4 dx[NV];
+#pragma unroll
+            for (int t = 0; t < NV; ++t) dx[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int qq = 0; qq < nq; ++qq) {
+                const float a = Ad[qq * Lk + r], d = Ds[qq * Lk + r];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const int c4 = lane + t * 64;
+                    if (c4 < nv) {
+                        const float4 gv = *reinterpret_cast<const float4*>(Gs + qq * D + c4 * 4);
+                        const float4 uv = *reinterpret_cast<const float4*>(Us + qq * D + c4 * 4);
+                        dx[t].x += a * gv.x + d * uv.x; dx[t].y += a * gv.y + d * uv.y;
+                        dx[t].z += a * gv.z + d * uv.z; dx[t].w += a * gv.w + d * uv.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int c4 = lane + t * 64;
+                if (c4 < nv) {
+                    float4* dst = reinterpret_cast<float4*>(p.dx + ((long)n * Lk + r) * D + c4 * 4);
+                    float4 v = dx[t];
+                    if (grp > 0) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+static int xattn_check(const char* who, int n_items, int H, int Lq, int Lk, int D) {
+    QT_CHECK_ARG(n_items > 0 && H > 0 && Lq > 0 && Lk > 0 && D > 0, "%s: bad sizes", who);
+    QT_CHECK_ARG(D % 4 == 0 && D <= 256 * XA_MAXV, "%s: D=%d must be a multiple of 4 and <= %d", who, D, 256 * XA_MAXV);
+    return QT_OK;
+}
+
+extern "C" int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
+                            int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
+                            float* ctx, float* lse, float* asum) {
+    if (int rc = xattn_check("qt_xattn_fwd", n_items, H, Lq, Lk, D)) return rc;
+    QT_CHECK_ARG(u && x && ctx && lse && asum, "qt_xattn_fwd: null pointer");
+    QT_CHECK_ARG(qt_aligned16(u) && qt_aligned16(x) && qt_aligned16(ctx), "qt_xattn_fwd: 16-byte alignment");
+    QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_xattn_fwd: drop_p=%f", drop_p);
+    XAttnArgs a; memset(&a, 0, sizeof(a));
+    a.u = u; a.x = x; a.ctx = ctx; a.lse = lse; a.asum = asum; a.u_is = u_is; a.u_rs = u_rs;
+    a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    const size_t lds = sizeof(float) * (size_t)XA_FCH * D;
+    const int nvl = (D / 4 + 63) / 64;                              // float4 per lane
+    hipStream_t st = (hipStream_t)stream;
+#define XA_FWD(NV_) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)qt_xattn_fwd_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                         hipLaunchKernelGGL(qt_xattn_fwd_kernel<NV_>, dim3(n_items), dim3(XA_NT), lds, st, a); } while (0)
+    if (nvl == 1) XA_FWD(1); else if (nvl == 2) XA_FWD(2); else if (nvl == 3) XA_FWD(3); else XA_FWD(4);
+#undef XA_FWD
+    QT_CHECK_LAUNCH("qt_xattn_fwd");
+    return QT_OK;
+}
+
+extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
+                            const float* ctx, const float* lse, const float* asum, const float* dctx, const float* dasum,
+                            int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
+                            float* du, float* dx) {
+    if (int rc = xattn_check("qt_xattn_bwd", n_items, H, Lq, Lk, D)) return rc;
+    QT_CHECK_ARG(u && x && ctx && lse && asum && dctx && du && dx, "qt_xattn_bwd: null pointer");
+    QT_CHECK_ARG(qt_aligned16(u) && qt_aligned16(x) && qt_aligned16(ctx) && qt_aligned16(dctx) && qt_aligned16(du) && qt_aligned16(dx),
+                 "qt_xattn_bwd: 16-byte alignment");
+    XAttnArgs a; memset(&a, 0, sizeof(a));
+    a.u = u; a.x = x; a.ctx_in = ctx; a.lse = (float*)lse; a.asum = (float*)asum; a.dctx = dctx; a.dasum = dasum;
+    a.u_is = u_is; a.u_rs = u_rs; a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.du = du; a.dx = dx;
+    const int NQ = Lq * H;
+    a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
+    size_t lds = 0;
+    for (a.bch = XA_BCH; a.bch >= 1; a.bch >>= 1) {
+        lds = sizeof(float) * ((size_t)a.bch * D + (size_t)2 * a.gq * D + (size_t)2 * a.gq * Lk);
+        if (lds <= 160 * 1024) break;
+    }
+    if (a.bch < 1) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_xattn_bwd: D=%d, Lk=%d, Lq*H=%d needs %zu B of LDS (>160 KiB)", D, Lk, NQ, lds);
+    const int nvl = (D / 4 + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define XA_BWD(NV_) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)qt_xattn_bwd_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                         hipLaunchKernelGGL(qt_xattn_bwd_kernel<NV_>, dim3(n_items), dim3(XA_NT), lds, st, a); } while (0)
+    if (nvl == 1) XA_BWD(1); else if (nvl == 2) XA_BWD(2); else if (nvl == 3) XA_BWD(3); else XA_BWD(4);
+#undef XA_BWD
+    QT_CHECK_LAUNCH("qt_xattn_bwd");
+    return QT_OK;
+}

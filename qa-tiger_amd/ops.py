@@ -127,7 +127,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
          bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: bool = False,
          mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
          accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, mode: str = 'fp32',
-         a_colsum: Optional[Tensor] = None) -> Tensor:
+         a_colsum: Optional[Tensor] = None, batch: Optional[Tuple[int, int, int, int]] = None) -> Tensor:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3."""
     a, b = as2d(a), as2d(b)
     _dev(a, b, bias, add, mask_src, out)
@@ -136,10 +136,12 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     if K != Kb:
         raise _lib.QTError(f'gemm: inner dimensions differ ({K} vs {Kb})')
     if out is None:
+        assert batch is None, 'batched gemm writes into a caller-provided view of the first problem'
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     else:
         out = out if out.dim() == 2 else out.reshape(-1, out.shape[-1])
         assert out.shape == (M, N) and out.stride(1) == 1
+    nb, a_bs, b_bs, c_bs = batch if batch is not None else (1, 0, 0, 0)
     if add is not None:
         add = as2d(add)
         assert add.shape == (M, N)
@@ -151,21 +153,22 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
             _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
             _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
             float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k))
+    btail = (int(nb), int(a_bs), int(b_bs), int(c_bs))
     if mode != 'fp32':
-        rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b), mode),
-                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum)))
+        rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), mode) + ((nb,) if nb > 1 else ()),
+                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail))
         if rc == 0:
             return out
         if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
             _lib.check(rc, 'qt_gemm_x3')
         if timer is not None:
             timer.records.pop()
-    rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b), 'fp32'), lambda: _lib.load().qt_gemm_f32(
+    rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), 'fp32') + ((nb,) if nb > 1 else ()), lambda: _lib.load().qt_gemm_f32(
         _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
         _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
         _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
-        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k)))
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), *btail))
     _lib.check(rc, 'qt_gemm_f32')
     if a_colsum is not None:                           # the fp32 kernel has no fused column sum
         _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), 0), 'qt_colsum')
@@ -330,6 +333,132 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float = 0.0, seed: int = 0) -> Tensor:
     return AttentionFn.apply(qbuf, kvbuf, spec, drop_p, seed)
+
+
+# --------------------------------------------------------------------------- #
+# few-query attention with the K/V projections folded away (csrc/xattn.hip)
+# --------------------------------------------------------------------------- #
+fold_kv = True      # PatchSelecter.crs_attn (Lq=2) and TempMoE.qst_attn (Lq=1) skip the K/V projection GEMMs
+
+
+class HeadExpandFn(torch.autograd.Function):
+    """U[:, h, :] = q[:, h-th d_h slice] @ W[h-th d_h rows, :]  — q [M, H*dh], W [H*dh, D] -> U [M, H*D].
+    With W = the key block of an MHA in-projection this is u_h = W_k,h^T q_h: the query moved to input space."""
+
+    @staticmethod
+    def forward(ctx, q: Tensor, w: Tensor, H: int):
+        q2, w2 = as2d(q), as2d(w)
+        M, E = q2.shape
+        D, dh = w2.shape[1], E // H
+        u = torch.empty((M, H * D), device=q2.device, dtype=torch.float32)
+        gemm(q2[:, :dh], w2[:dh], trans_b=False, out=u[:, :D], batch=(H, dh, dh * D, D), mode=precision['fwd'])
+        ctx.save_for_backward(q2, w2)
+        ctx.H = H
+        return u
+
+    @staticmethod
+    def backward(ctx, du: Tensor):
+        q2, w2 = ctx.saved_tensors
+        H = ctx.H
+        M, E = q2.shape
+        D, dh = w2.shape[1], E // H
+        du = as2d(du.contiguous())
+        dq = dw = None
+        if ctx.needs_input_grad[0]:
+            dq = torch.empty_like(q2)
+            gemm(du[:, :D], w2[:dh], trans_b=True, out=dq[:, :dh], batch=(H, D, dh * D, dh), mode=precision['bwd'])
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w2)
+            gemm(q2[:, :dh], du[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'])
+        return dq, dw, None
+
+
+class HeadContractFn(torch.autograd.Function):
+    """o[:, h-th d_h slice] = ctx[:, h, :] @ W[h-th d_h rows, :]^T  — ctx [M, H*D], W [H*dh, D] -> o [M, H*dh]
+    (the value block of the in-projection applied AFTER the attention-weighted sum of raw rows)."""
+
+    @staticmethod
+    def forward(ctx_, c: Tensor, w: Tensor, H: int):
+        c2, w2 = as2d(c), as2d(w)
+        M = c2.shape[0]
+        D = w2.shape[1]
+        dh = w2.shape[0] // H
+        o = torch.empty((M, H * dh), device=c2.device, dtype=torch.float32)
+        gemm(c2[:, :D], w2[:dh], trans_b=True, out=o[:, :dh], batch=(H, D, dh * D, dh), mode=precision['fwd'])
+        ctx_.save_for_backward(c2, w2)
+        ctx_.H = H
+        return o
+
+    @staticmethod
+    def backward(ctx_, do: Tensor):
+        c2, w2 = ctx_.saved_tensors
+        H = ctx_.H
+        D = w2.shape[1]
+        dh = w2.shape[0] // H
+        do = as2d(do.contiguous())
+        dc = dw = None
+        if ctx_.needs_input_grad[0]:
+            dc = torch.empty_like(c2)
+            gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'])
+        if ctx_.needs_input_grad[1]:
+            dw = torch.empty_like(w2)
+            gemm(do[:, :dh], c2[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'])
+        return dc, dw, None
+
+
+class FoldAttnFn(torch.autograd.Function):
+    """(u [rows, H*D], x [n_items*Lk, D]) -> ctx [rows, H*D], asum [rows, H]; see include/qatiger.h qt_xattn_fwd."""
+
+    @staticmethod
+    def forward(ctx_, u: Tensor, x: Tensor, n_items: int, H: int, Lq: int, Lk: int, u_is: int, u_rs: int,
+                scale: float, drop_p: float, seed: int):
+        u2, x2 = as2d(u).contiguous(), as2d(x).contiguous()
+        _dev(u2, x2)
+        D = x2.shape[1]
+        rows = u2.shape[0]
+        assert u2.shape[1] == H * D and x2.shape[0] == n_items * Lk
+        c = torch.empty_like(u2)
+        lse = torch.empty((rows * H,), device=u2.device, dtype=torch.float32)
+        asum = torch.empty((rows, H), device=u2.device, dtype=torch.float32)
+        nbytes = 4.0 * D * (2 * rows * H + n_items * Lk)
+        rc = _launch('attn_fwd', nbytes, ('fold', n_items, Lq, Lk, D), lambda: _lib.load().qt_xattn_fwd(
+            _stream(), _ptr(u2), u_is, u_rs, _ptr(x2), n_items, H, Lq, Lk, D, float(scale), float(drop_p), C.c_ulonglong(seed),
+            _ptr(c), _ptr(lse), _ptr(asum)))
+        _lib.check(rc, 'qt_xattn_fwd')
+        ctx_.save_for_backward(u2, x2, c, lse, asum)
+        ctx_.cfg = (n_items, H, Lq, Lk, D, u_is, u_rs, scale, drop_p, seed, u.shape, x.shape)
+        return c, asum
+
+    @staticmethod
+    def backward(ctx_, dc: Tensor, dasum: Optional[Tensor]):
+        u2, x2, c, lse, asum = ctx_.saved_tensors
+        n_items, H, Lq, Lk, D, u_is, u_rs, scale, drop_p, seed, ushape, xshape = ctx_.cfg
+        dc = as2d(dc.contiguous())
+        dasum = None if dasum is None else dasum.contiguous()
+        du, dx = torch.empty_like(u2), torch.empty_like(x2)
+        nbytes = 4.0 * D * (4 * u2.shape[0] * H + 2 * n_items * Lk)
+        rc = _launch('attn_bwd', nbytes, ('fold', n_items, Lq, Lk, D), lambda: _lib.load().qt_xattn_bwd(
+            _stream(), _ptr(u2), u_is, u_rs, _ptr(x2), _ptr(c), _ptr(lse), _ptr(asum), _ptr(dc), _ptr(dasum),
+            n_items, H, Lq, Lk, D, float(scale), float(drop_p), C.c_ulonglong(seed), _ptr(du), _ptr(dx)))
+        _lib.check(rc, 'qt_xattn_bwd')
+        return du.reshape(ushape), dx.reshape(xshape), None, None, None, None, None, None, None, None, None
+
+
+def folded_attention(q: Tensor, x: Tensor, mha, n_items: int, Lq: int, Lk: int, u_is: int, u_rs: int,
+                     drop_p: float, seed: int) -> Tensor:
+    """MHA(query rows q (already q-projected, [rows, E]), key = value = raw rows x [n_items*Lk, E]) WITHOUT the
+    K/V in-projection GEMMs; returns the attention output before the out-projection, [rows, E].
+    `mha` is the nn.MultiheadAttention parameter container."""
+    E, H = mha.embed_dim, mha.num_heads
+    dh = E // H
+    W, b = mha.in_proj_weight, mha.in_proj_bias
+    u = HeadExpandFn.apply(q, W[E:2 * E], H)                                    # W_k folded into the query
+    c, asum = FoldAttnFn.apply(u, x, n_items, H, Lq, Lk, u_is, u_rs, 1.0 / math.sqrt(dh), drop_p, seed)
+    o = HeadContractFn.apply(c, W[2 * E:], H)                                   # W_v after the weighted sum
+    # + b_v,h * sum_p a_h[p]   (sum = 1 unless attention-probability dropout is active)
+    head_of = torch.arange(E, device=q.device) // dh
+    wb = b[2 * E:, None] * (head_of[:, None] == torch.arange(H, device=q.device)[None, :]).to(b.dtype)   # [E, H]
+    return linear(asum, wb, None, residual=o)
 
 
 # --------------------------------------------------------------------------- #

@@ -18,6 +18,9 @@ execution plan is not the reference's:
     head-split permutes), batch-first throughout (the reference permutes to
     (L,N,E) at every call);
   * residual + dropout + LayerNorm are one kernel;
+  * attentions with one or two queries (TempMoE.qst_attn, PatchSelecter.crs_attn) never project
+    K and V: W_k is folded into the query, W_v is applied after the attention-weighted sum of the raw
+    rows (csrc/xattn.hip, SURVEY.md §7);
   * TempMoE runs all experts' first layers as one GEMM, reduces over time with
     the quirk-exact coefficient table, and applies the second layers after the
     reduction (linear), never materialising the (T,B,K,D) stack
@@ -209,8 +212,11 @@ class TempMoE(nn.Module):
         pa = self.qst_attn.dropout if self.training else 0.0
         # question -> time attention (Lq = 1)
         q = ops.linear(qst, *_mha_proj(self.qst_attn, 'q'))
-        kv = ops.linear(data, *_mha_proj(self.qst_attn, 'kv'))
-        o = ops.attention(q, kv, AttnSpec(B, B, 0, H, 1, T, D, 0, 0, D), pa, ops.seeds.next())
+        if ops.fold_kv:     # one query per sample: fold W_k into it, apply W_v after the weighted sum (no K/V GEMM over B*T rows)
+            o = ops.folded_attention(q, data.reshape(B * T, D), self.qst_attn, B, 1, T, 1, 0, pa, ops.seeds.next())
+        else:
+            kv = ops.linear(data, *_mha_proj(self.qst_attn, 'kv'))
+            o = ops.attention(q, kv, AttnSpec(B, B, 0, H, 1, T, D, 0, 0, D), pa, ops.seeds.next())
         temp_w = ops.linear(o, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias)          # [B,D]
         logits = ops.linear(temp_w, self.router[0].weight, self.router[0].bias)                      # [B,K]
         raw = ops.linear(temp_w, self.gauss_pred[0].weight, self.gauss_pred[0].bias)                 # [B,2K]
@@ -263,10 +269,13 @@ class PatchSelecter(nn.Module):
         o = ops.attention(qkv, None, AttnSpec(BT, BT, 0, H, P, P, D, 0, D, 2 * D), p, nxt())
         psa = ops.linear(o, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias, residual=pp)
         # two queries per frame — row 0 video, row 1 audio (modules.py:692) — stacked as [video; audio]
-        kv = ops.linear(psa, *_mha_proj(self.crs_attn, 'kv'))
         y2 = torch.cat([video.reshape(BT, D), audio.reshape(BT, D)], dim=0)
         qc = ops.linear(y2, *_mha_proj(self.crs_attn, 'q'))
-        o_c = ops.attention(qc, kv, AttnSpec(BT, BT, 0, H, 2, P, D, 0, 0, D, q_is=1, q_rs=BT, o_rows=2 * BT), p, nxt())
+        if ops.fold_kv:     # 2 queries against P patch rows: the K/V projection of all B*T*P rows (17 % of the path's GEMM FLOPs) is folded away
+            o_c = ops.folded_attention(qc, psa, self.crs_attn, BT, 2, P, 1, BT, p, nxt())
+        else:
+            kv = ops.linear(psa, *_mha_proj(self.crs_attn, 'kv'))
+            o_c = ops.attention(qc, kv, AttnSpec(BT, BT, 0, H, 2, P, D, 0, 0, D, q_is=1, q_rs=BT, o_rows=2 * BT), p, nxt())
         a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias, drop_p=p, seed=nxt())
         m = ops.linear(ops.linear(a_c, self.mlp[0].weight, self.mlp[0].bias, relu=True), self.mlp[2].weight, self.mlp[2].bias)
         v_rel, a_rel = m[:BT], m[BT:]

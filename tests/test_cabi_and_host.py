@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(qt):
 
 def test_bad_arguments_return_error_codes_without_a_gpu(qt):
     lib = importlib.import_module('qa-tiger_amd._lib').load()
-    rc = lib.qt_gemm_f32(None, 0, 1, 0, 4, 4, 1.0, None, 4, None, 4, None, 4, None, None, 0, 0, None, 0, 1.0, 0.0, 0, 0, 0)
+    rc = lib.qt_gemm_f32(None, 0, 1, 0, 4, 4, 1.0, None, 4, None, 4, None, 4, None, None, 0, 0, None, 0, 1.0, 0.0, 0, 0, 0, 1, 0, 0, 0)
     assert rc == -2 and b'empty problem' in lib.qt_last_error()
     rc = lib.qt_moe_router_fwd(None, None, None, 1, 1, 1, 1, None, None, None, None)
     assert rc == -2 and b'null pointer' in lib.qt_last_error()

@@ -299,6 +299,48 @@ def test_attention_streaming_dropout_consistency(ops):
         assert abs(lhs - rhs) < 2e-2 * max(1e-3, abs(lhs)) + 1e-4
 
 
+@pytest.mark.parametrize('n_items,Lq,Lk,E,u_is,u_rs', [(24, 2, 14, 768, 1, 24), (16, 1, 60, 768, 1, 0), (6, 1, 300, 1024, 1, 0),
+                                                      (10, 2, 3, 64, 1, 10), (7, 1, 7, 512, 1, 0)])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_folded_attention_matches_projected_attention(ops, n_items, Lq, Lk, E, u_is, u_rs, p):
+    """K/V-folded few-query attention == nn.MultiheadAttention math with explicit K/V projections (fp64),
+    forward and every gradient (q, raw rows, in-projection weight and bias)."""
+    H, dh = 8, E // 8
+    torch.manual_seed(0)
+    mha = torch.nn.MultiheadAttention(E, H).to(DEV)
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.05)
+    rows = n_items * Lq
+    q = rnd(rows, E, seed=41).requires_grad_(True)
+    x = rnd(n_items * Lk, E, seed=42).requires_grad_(True)
+    o = ops.folded_attention(q, x, mha, n_items, Lq, Lk, u_is, u_rs, p, 11)
+    if p > 0:       # statistical check only: deterministic for a seed, mean preserved
+        o2 = ops.folded_attention(q, x, mha, n_items, Lq, Lk, u_is, u_rs, p, 11)                  # same seed -> same mask
+        assert rel(o2, o) < 1e-5                                  # (split-K atomics: last-bit differences only)
+        assert rel(ops.folded_attention(q, x, mha, n_items, Lq, Lk, u_is, u_rs, p, 12), o) > 1e-3
+        o.backward(rnd(rows, E, seed=43))
+        assert torch.isfinite(q.grad).all() and torch.isfinite(x.grad).all() and torch.isfinite(mha.in_proj_weight.grad).all()
+        return
+    go = rnd(rows, E, seed=43)
+    o.backward(go)
+    W, b = mha.in_proj_weight.detach().double().requires_grad_(True), mha.in_proj_bias.detach().double().requires_grad_(True)
+    qr, xr = q.detach().double().requires_grad_(True), x.detach().double().requires_grad_(True)
+    k = (xr @ W[E:2 * E].t() + b[E:2 * E]).reshape(n_items, Lk, E)
+    v = (xr @ W[2 * E:].t() + b[2 * E:]).reshape(n_items, Lk, E)
+    idx = torch.arange(n_items, device=DEV)
+    qq = torch.stack([qr[(idx * u_is + i * u_rs)] for i in range(Lq)], 1)     # [n, Lq, E]
+    ref = ref_attention(qq, k, v, H)
+    out_ref = torch.zeros(rows, E, dtype=torch.double, device=DEV)
+    for i in range(Lq):
+        out_ref = out_ref.index_add(0, idx * u_is + i * u_rs, ref[:, i])
+    out_ref.backward(go.double())
+    assert rel(o, out_ref) < 5e-6
+    assert rel(q.grad, qr.grad) < 1e-4 and rel(x.grad, xr.grad) < 1e-4
+    gW, gb = mha.in_proj_weight.grad, mha.in_proj_bias.grad
+    assert rel(gW[E:], W.grad[E:]) < 1e-4 and rel(gb[2 * E:], b.grad[2 * E:]) < 1e-4
+    assert float(gb[:2 * E].abs().max()) == 0 and float(gW[:E].abs().max()) == 0   # q block not used here; key bias has zero true gradient
+
+
 def test_attention_unsupported_shape_fails_loudly(ops, qt):
     E, H, L = 192, 8, 300                                  # d_h = 24: neither MFMA path applies and the generic kernel needs > 160 KiB
     qkv = torch.zeros(L, 3 * E, device=DEV)
