@@ -261,6 +261,23 @@ def test_train_mode_dropout_and_loss_decreases(qt, synth):
     assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.3
 
 
+def test_training_soak_at_real_dims(qt, synth):
+    """40 train steps at the ViT-L/14 shape (T=60, D=768, K=8, B=16), dropout on, split-precision GEMMs:
+    loss and every parameter / moment stay finite and the loss on the fixed batch goes down."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 16})
+    torch.manual_seed(1)
+    qt.ops.seeds.reset()
+    model = qt.QA_TIGER(**cfg.model_kwargs()).to(DEV).train()
+    eng = qt.DataParallelStep(model, lr=1e-4, betas=(0.95, 0.999))
+    batch = qt.synth.fast_device_inputs(cfg, DEV, seed=3)
+    losses = [float(eng.step(batch)) for _ in range(40)]
+    assert all(np.isfinite(losses)), losses
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.2, (losses[:5], losses[-5:])
+    for t in (eng.flat.flat, eng.flat.grad, eng.optim.exp_avg, eng.optim.exp_avg_sq):
+        assert bool(torch.isfinite(t).all())
+    assert eng.optim.step_count == 40
+
+
 def test_cpu_tensors_fail_loudly(qt, synth):
     cfg = synth.CONFIG_TOY
     model = qt.QA_TIGER(**cfg.model_kwargs())
