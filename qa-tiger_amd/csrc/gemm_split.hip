@@ -50,7 +50,7 @@ struct GemmArgs {          // identical to gemm.hip
     int k_per_split;
     int tiles_n;
     int tiles_m;
-    long a_bs, b_bs, c_bs;    // element strides between the gridDim.z problems of a batched launch (heads)
+    int batch; long a_bs, b_bs, c_bs;   // batched launch (one problem per attention head): count and element strides
     float* a_colsum;          // transA only: a_colsum[m] += sum_k A[k,m]  (bias gradient riding on the dW GEMM)
 };
 
@@ -106,26 +106,42 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     static_assert(LA * 4 == BM * SBK / NT && LB * 4 == BN * SBK / NT, "tile/threads mismatch");
     static_assert(NT % BM == 0 && NT % BN == 0, "K-slow staging needs NT multiple of the tile edge");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    p.A += (long)blockIdx.z * p.a_bs; p.B += (long)blockIdx.z * p.b_bs; p.C += (long)blockIdx.z * p.c_bs;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NWN, wn = wave - wm * NWN;
     const int r = lane & 31, h = lane >> 5;
+    const float* const A0 = p.A; const float* const B0 = p.B; float* const C0 = p.C;
 
-    const int nwg = gridDim.x, orig = blockIdx.x;                  // XCD-aware tile order (see gemm.hip)
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    // Inside an XCD's contiguous chunk, walk groups of GM M-tiles: M fastest, then N, so the workgroups
-    // resident on an XCD cover a compact window of tiles and share A and B panels through its 4 MiB L2
-    // (a plain N-fastest walk needs every B panel at once: 7 MB at N=2304, 49 % L2 hits measured).
+    // Persistent workgroups: the grid is one round of resident workgroups and each walks the work
+    // items  w = blockIdx.x, blockIdx.x + gridDim.x, ...  (work item = (tile, K split, batch)).
+    // The C write-out of a tile (22 % of the kernel at K = 768 when it was exposed) then drains
+    // behind the next tile's loads and MFMAs.  Inside a round, the workgroups of one XCD
+    // (blockIdx % 8, round-robin dispatch) take a contiguous run of tiles, walked M-fastest inside
+    // groups of GM M-tiles, so an XCD's resident workgroups cover a compact window of tiles and
+    // share A and B panels through its 4 MiB L2 (N-fastest order: 49 % L2 hits measured).
     constexpr int GM = (BM == 128) ? 8 : 4;
-    const int group = wgid / (GM * p.tiles_n);
-    const int gm_rows = min(GM, p.tiles_m - group * GM);
-    const int within = wgid - group * (GM * p.tiles_n);
-    const int tile_n = within / gm_rows, tile_m = group * GM + (within - tile_n * gm_rows);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = blockIdx.y * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+    const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);   // bijective on [0,G)
+    const int tiles = p.tiles_m * p.tiles_n;
+    const long total = (long)tiles * p.split_k * p.batch;
+    int m0 = 0, n0 = 0, kbeg = 0, kend = 0, tile_n = 0, ksplit = 0;
+    auto decode3 = [&](int t, int ks, int z) {                      // sets m0, n0, kbeg, kend, operand bases
+        ksplit = ks;
+        const int group = t / (GM * p.tiles_n);
+        const int gm_rows = min(GM, p.tiles_m - group * GM);
+        const int within = t - group * (GM * p.tiles_n);
+        tile_n = within / gm_rows;
+        m0 = (group * GM + (within - tile_n * gm_rows)) * BM;
+        n0 = tile_n * BN;
+        kbeg = ksplit * p.k_per_split;
+        kend = min(p.K, kbeg + p.k_per_split);
+        p.A = A0 + (long)z * p.a_bs; p.B = B0 + (long)z * p.b_bs; p.C = C0 + (long)z * p.c_bs;
+    };
+    auto decode = [&](long w) {
+        const long rest = w / tiles;
+        decode3((int)(w - rest * tiles), (int)(rest % p.split_k), (int)(rest / p.split_k));
+    };
 
     floatx16 acc[WMT][WNT];
 #pragma unroll
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     // K-contiguous operand: float4s, thread -> (row = kc_row(idx), k-quad = idx&7)
     // K-slow operand: coalesced dwords, thread -> (col = tid % edge, 32*edge/NT consecutive k)
     unsigned offA[LA], offB[LB];
-    {
+    auto set_offsets = [&]() {
 #pragma unroll
         for (int it = 0; it < LA; ++it) {
             const int idx = tid + it * NT;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
         if (TA) offA[0] = (unsigned)(((long)((tid / BM) * (LA * 4)) * p.lda + min(m0 + (tid % BM), p.M - 1)) * 4);
         if (!TB) offB[0] = (unsigned)(((long)((tid / BN) * (LB * 4)) * p.ldb + min(n0 + (tid % BN), p.N - 1)) * 4);
-    }
+    };
     // `full` is a compile-time tag: the hot path (whole BK inside [kbeg,kend)) is straight-line
     // loads; only the last, partial tile of a K range takes the predicated build.
     auto load_kc = [&](const float* base, const auto& off, int k0, auto full, auto& dst) {
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
     };
     float csum = 0.f;                                               // this thread's share of a_colsum (TA only)
-    const bool do_csum = TA && p.a_colsum != nullptr && tile_n == 0;
+    bool do_csum = false;
     auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src) {
         constexpr int KN = sizeof(src) / sizeof(src[0]);
         const int col = tid % edge, kb = (tid / edge) * KN;
@@ -268,45 +284,77 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
     };
 
-    const int nk = (kend - kbeg + SBK - 1) / SBK;
-    if constexpr (PREF == 2) {
-        // while tile t feeds the MFMAs from LDS, tile t+1 sits in one register set and the loads of
-        // tile t+2 are in flight into the other: every load has ~2 iterations to land
-        if (nk > 0) { gload(kbeg, ra0, rb0); sstore(0, ra0, rb0); }
-        if (nk > 1) gload(kbeg + SBK, ra0, rb0);
-        __syncthreads();
-        for (int t = 0; t < nk; t += 2) {
-            if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra1, rb1);
-            compute(0);
-            if (t + 1 < nk) sstore(1, ra0, rb0);
-            __syncthreads();
-            if (t + 1 >= nk) break;
-            if (t + 3 < nk) gload(kbeg + (t + 3) * SBK, ra0, rb0);
-            compute(1);
-            if (t + 2 < nk) sstore(0, ra1, rb1);
-            __syncthreads();
-        }
+    constexpr bool PERSIST = (PREF == 1);   // big tile only: the small tile (2 workgroups/CU) is launched one item per workgroup
+    long w = slot;
+    if constexpr (PERSIST) {
+        if (w >= total) return;
+        decode(w);
     } else {
-        if (nk > 0) { gload(kbeg, ra0, rb0); sstore(0, ra0, rb0); }
-        __syncthreads();
-        for (int t = 0; t < nk; ++t) {
-            if (t + 1 < nk) gload(kbeg + (t + 1) * SBK, ra0, rb0);
-            compute(t & 1);
-            if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
-            __syncthreads();
-        }
+        decode3(slot, blockIdx.y, blockIdx.z);                      // grid = (tiles, split_k, batch)
     }
-
-    if (do_csum && m0 + (tid % BM) < p.M) atomicAdd(p.a_colsum + m0 + (tid % BM), csum);
+    set_offsets();
+    if (kend > kbeg) gload(kbeg, ra0, rb0);                         // first tile of the first work item
+    for (;;) {
+        do_csum = TA && p.a_colsum != nullptr && tile_n == 0;
+        csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int nk = (kend - kbeg + SBK - 1) / SBK;
+        // registers already hold tile 0 of this work item (loaded before the previous epilogue)
+        if constexpr (PREF == 2) {
+            // while tile t feeds the MFMAs from LDS, tile t+1 sits in one register set and the loads of
+            // tile t+2 are in flight into the other: every load has ~2 iterations to land
+            if (nk > 0) sstore(0, ra0, rb0);
+            if (nk > 1) gload(kbeg + SBK, ra0, rb0);
+            __syncthreads();
+            for (int t = 0; t < nk; t += 2) {
+                if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra1, rb1);
+                compute(0);
+                if (t + 1 < nk) sstore(1, ra0, rb0);
+                __syncthreads();
+                if (t + 1 >= nk) break;
+                if (t + 3 < nk) gload(kbeg + (t + 3) * SBK, ra0, rb0);
+                compute(1);
+                if (t + 2 < nk) sstore(0, ra1, rb1);
+                __syncthreads();
+            }
+        } else {
+            if (nk > 0) sstore(0, ra0, rb0);
+            __syncthreads();
+            for (int t = 0; t < nk; ++t) {
+                if (t + 1 < nk) gload(kbeg + (t + 1) * SBK, ra0, rb0);
+                compute(t & 1);
+                if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
+                __syncthreads();
+            }
+        }
+        // this work item's output coordinates, kept for the epilogue while the NEXT item's loads go out
+        const int em0 = m0, en0 = n0;
+        float* const eC = p.C;
+        const bool first_split = (ksplit == 0);
+        if (do_csum && m0 + (tid % BM) < p.M) atomicAdd(p.a_colsum + m0 + (tid % BM), csum);
+        w += G;
+        const bool more = w < total;
+        // big tile (1 workgroup/CU): nothing else on the CU hides the write-out, so the next item's first
+        // loads go out before it.  The small tile runs 2 workgroups/CU and has no registers to spare for this.
+        constexpr bool EARLY = PERSIST;
+        if (EARLY && more) {
+            decode(w);
+            set_offsets();
+            if (kend > kbeg) gload(kbeg, ra0, rb0);                 // older than the stores below in the vmcnt queue
+        }
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // At K = 768 a tile has only 24 BK steps, so the epilogue's instruction count matters (a first
     // version with per-element 64-bit addressing and six runtime flags ran the residual out-projection
     // at 148 TFLOP/s against 305 for the plain store).  One row pointer per output row; the feature
     // set is a compile-time tag: plain (bias [+ReLU] store or split-K atomics), +residual, or full
     // (mask / dropout / accumulate).
-    const bool first_split = (blockIdx.y == 0);
-    const int mrow0 = m0 + wm * (WMT * 32) + 4 * h;
-    const int ncol0 = n0 + wn * (WNT * 32) + r;
+    const int mrow0 = em0 + wm * (WMT * 32) + 4 * h;
+    const int ncol0 = en0 + wn * (WNT * 32) + r;
     float bias_v[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
@@ -337,7 +385,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                         if (has_add) addv[e8][j] = use_add ? p.add_src[mc * p.ld_add + ncl[j]] : 0.f;
                         if (full) {
                             mskv[e8][j] = p.mask_src ? p.mask_src[mc * p.ld_mask + ncl[j]] : 1.f;
-                            oldv[e8][j] = p.accumulate ? p.C[mc * p.ldc + ncl[j]] : 0.f;
+                            oldv[e8][j] = p.accumulate ? eC[mc * p.ldc + ncl[j]] : 0.f;
                         }
                     }
                 }
@@ -346,7 +394,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                     const int e = eh * 8 + e8;
                     const int m = mrow0 + i * 32 + (e & 3) + 8 * (e >> 2);
                     if (m < p.M) {
-                        float* crow = p.C + (long)m * p.ldc + ncol0;
+                        float* crow = eC + (long)m * p.ldc + ncol0;
                         static_for<WNT>([&](auto J) {
                             constexpr int j = decltype(J)::value;
                             if (ncol0 + j * 32 < p.N) {
@@ -372,6 +420,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         if (p.add_src) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
     } else if (p.add_src) epilogue(std::true_type{}, std::false_type{});
     else epilogue(std::false_type{}, std::false_type{});
+        if (!PERSIST || !more) break;
+    }
 }
 
 template <int WMT, int WNT, int NWM, int NWN, int PREF, int HT>
@@ -426,7 +476,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
-    a.a_colsum = a_colsum; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
+    a.a_colsum = a_colsum; a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
 
@@ -475,7 +525,10 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
     }
     QT_CHECK_ARG(tiles < (1L << 31), "qt_gemm_x3: grid too large");
+    const long total_work = tiles * split_k * batch;
+    // big tile: persistent, one resident round of workgroups walks all work items; small tile: one item each
     dim3 grid((unsigned)tiles, (unsigned)split_k, (unsigned)batch);
+    if (big) grid = dim3((unsigned)(total_work > slots ? slots : total_work));
     if (big) { if (half_type == 0) launch_x3<4, 2, 2, 4, 1, 0>(a, transA, transB, grid, st); else launch_x3<4, 2, 2, 4, 1, 1>(a, transA, transB, grid, st); }
     else     { if (half_type == 0) launch_x3<2, 2, 2, 2, 2, 0>(a, transA, transB, grid, st); else launch_x3<2, 2, 2, 2, 2, 1>(a, transA, transB, grid, st); }
     QT_CHECK_LAUNCH("qt_gemm_x3");
