@@ -284,6 +284,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
     };
 
+    const bool late = (PREF == 1) && __builtin_amdgcn_readfirstlane(wave) >= (NWM * NWN) / 2;
     constexpr bool PERSIST = (PREF == 1);   // big tile only: the small tile (2 workgroups/CU) is launched one item per workgroup
     long w = slot;
     if constexpr (PERSIST) {
@@ -323,12 +324,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                 __syncthreads();
             }
         } else {
+            // 8 waves = 2 per SIMD, one barrier per K tile.  Run in lock-step, both waves of a SIMD convert
+            // together (matrix pipe idle) and then compete for the matrix pipe.  Waves 4-7 therefore run
+            // half an iteration out of phase: they convert + store tile t+1 FIRST (its loads were issued an
+            // iteration earlier), then multiply tile t, so a SIMD's matrix pipe sees one wave's MFMAs beside
+            // the other wave's VALU/LDS-store work.  Same LDS buffers, same barrier count, same results.
             if (nk > 0) sstore(0, ra0, rb0);
+            if (nk > 1) gload(kbeg + SBK, ra0, rb0);
             __syncthreads();
+            // both halves issue the loads of tile t+2 as soon as tile t+1 has left the registers: the early
+            // half before it waits at the barrier, so its loads also fly during that wait
             for (int t = 0; t < nk; ++t) {
-                if (t + 1 < nk) gload(kbeg + (t + 1) * SBK, ra0, rb0);
+                if (late) {
+                    if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
+                    if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra0, rb0);
+                }
                 compute(t & 1);
-                if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
+                if (!late) {
+                    if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
+                    if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra0, rb0);
+                }
                 __syncthreads();
             }
         }
@@ -480,11 +495,12 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
 
-    // Tile choice (measured, tools/bench_gemm.py): the 256x256 tile needs half the operand bytes per FLOP
-    // but owns a whole CU; it wins (+20 %) on the M = B*T*P GEMMs and their dW (one dimension in the
-    // hundreds of thousands: many rounds, long K loops) and loses on the 30720-row ones.
-    const long dmax = M > N ? (M > K ? M : K) : (N > K ? N : K);
-    bool big = (M >= 256 && N >= 256) && dmax >= 65536;
+    // Tile choice (measured, tools/bench_gemm.py, profiles/r01_v10_gemm_microbench.txt): the 256x256 tile
+    // needs half the operand bytes per FLOP but owns a whole CU.  Since it became persistent (write-out
+    // hidden behind the next tile) and its wave halves run staggered it wins on every shape of the path
+    // that has 256 rows and columns, +2..30 % over the 128x128 tile.
+    bool big = (M >= 256 && N >= 256);
+    if (K < 512 && (long)((M + 255) / 256) * ((N + 255) / 256) * batch < 128) big = false;   // too few 256-tiles and no K to split
     if (force == 1) big = false;
     if (force == 2) big = true;
     const int BT = big ? 256 : 128;
