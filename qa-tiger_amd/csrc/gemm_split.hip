@@ -58,15 +58,26 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-template <int HT> __device__ inline void split2(float x, u16& hi, u16& lo) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// Two elements at a time: one packed convert for the hi parts, the hi parts widened back with
+// shifts/masks (bf16) or v_cvt_f32_f16 (fp16), one packed subtract, one packed convert for the lo
+// parts: 5 VALU instructions per pair.
+template <int HT> __device__ inline void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 x = {x0, x1};
     if (HT == 0) {
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)(x - (float)h);
-        hi = __builtin_bit_cast(u16, h); lo = __builtin_bit_cast(u16, l);
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 d = x - __builtin_convertvector(h, f32x2);
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, f16x2));
     } else {
-        const __bf16 h = (__bf16)x;
-        const __bf16 l = (__bf16)(x - (float)h);
-        hi = __builtin_bit_cast(u16, h); lo = __builtin_bit_cast(u16, l);
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        hi = __builtin_bit_cast(unsigned, h);
+        const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+        const f32x2 d = x - hf;
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
     }
 }
 
@@ -205,12 +216,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         for (int it = 0; it < L; ++it) {
             const int idx = tid + it * NT;
             const int row = kc_row(idx), kq = idx & 7;
-            u16 hh[4], ll[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2<HT>(src[it * 4 + e], hh[e], ll[e]);
             uint2 vh, vl;
-            vh.x = hh[0] | ((unsigned)hh[1] << 16); vh.y = hh[2] | ((unsigned)hh[3] << 16);
-            vl.x = ll[0] | ((unsigned)ll[1] << 16); vl.y = ll[2] | ((unsigned)ll[3] << 16);
+            split_pair<HT>(src[it * 4 + 0], src[it * 4 + 1], vh.x, vl.x);
+            split_pair<HT>(src[it * 4 + 2], src[it * 4 + 3], vh.y, vl.y);
             *reinterpret_cast<uint2*>(hi_img + row * SLD + kq * 4) = vh;
             *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
         }
@@ -222,14 +230,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         const int col = tid % edge, kb = (tid / edge) * KN;
 #pragma unroll
         for (int e = 0; e < KN / 8; ++e) {
-            u16 hh[8], ll[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) split2<HT>(src[e * 8 + j], hh[j], ll[j]);
             uint4 vh, vl;
-            vh.x = hh[0] | ((unsigned)hh[1] << 16); vh.y = hh[2] | ((unsigned)hh[3] << 16);
-            vh.z = hh[4] | ((unsigned)hh[5] << 16); vh.w = hh[6] | ((unsigned)hh[7] << 16);
-            vl.x = ll[0] | ((unsigned)ll[1] << 16); vl.y = ll[2] | ((unsigned)ll[3] << 16);
-            vl.z = ll[4] | ((unsigned)ll[5] << 16); vl.w = ll[6] | ((unsigned)ll[7] << 16);
+            split_pair<HT>(src[e * 8 + 0], src[e * 8 + 1], vh.x, vl.x);
+            split_pair<HT>(src[e * 8 + 2], src[e * 8 + 3], vh.y, vl.y);
+            split_pair<HT>(src[e * 8 + 4], src[e * 8 + 5], vh.z, vl.z);
+            split_pair<HT>(src[e * 8 + 6], src[e * 8 + 7], vh.w, vl.w);
             *reinterpret_cast<uint4*>(hi_img + col * SLD + kb + e * 8) = vh;
             *reinterpret_cast<uint4*>(lo_img + col * SLD + kb + e * 8) = vl;
         }
