@@ -42,7 +42,7 @@ const char* qt_last_error(void);
  * problem z uses A + z*a_bs, B + z*b_bs, C + z*c_bs (element strides); no bias/residual/mask then. */
 int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
                 const float* A, long lda, const float* B, long ldb, float* C, long ldc,
-                const float* bias, const float* add_src, long ld_add, int relu,
+                const float* bias, const float* add_src, long ld_add, int relu /* 0 none, 1 ReLU, 2 QuickGELU (clip_base.py:166-168) */,
                 const float* mask_src, long ld_mask, float mask_scale,
                 float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
                 int batch, long a_bs, long b_bs, long c_bs);
@@ -148,6 +148,29 @@ int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long*
  * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce). */
 int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                  int step, float lr, float beta1, float beta2, float eps, float grad_scale);
+
+/* ---- frozen CLIP text tower (forward only) and evaluation counters ---- */
+
+/* Causal self-attention core of the text transformer: softmax(q k^T * scale + mask) v with the additive
+ * -inf upper-triangular mask of reference src/models/base/clip_base.py:390-396, called from
+ * ResidualAttentionBlock.attention (:211-214).  Addressing as qt_attn_fwd; Lq = Lk = L; no dropout. */
+int qt_attn_causal_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                       const float* k, long ldk, const float* v, long ldv, long kv_is,
+                       float* o, long ldo, long o_is, long o_rs,
+                       int n_items, int H, int L, int dh, float scale);
+/* out[b,l,:] = token_embedding[text[b,l],:] + positional_embedding[l,:]  (src/models/encoders.py:31-32).
+ * text is int32 [B,L] (the dtype the reference feeds, src/trainutils.py:226); ids outside [0,vocab) are clamped. */
+int qt_text_embed_fwd(void* stream, const int* text, int B, int L, int W, int vocab,
+                      const float* token_embedding, const float* positional_embedding, float* out);
+/* out[b,:] = x[b, argmax_l text[b,l], :] — the EOT-token feature (src/models/encoders.py:37); first maximum wins.
+ * eot_index (nullable) receives the chosen positions. */
+int qt_text_eot_rows(void* stream, const int* text, int B, int L, int W, const float* x, float* out, int* eot_index);
+/* Evaluation counters (src/trainutils.py:338-346, 417-423): predicted[b] = argmax_c logits[b,c] (nullable),
+ * totals[0] += B, totals[1] += #correct; with qtype (int32 [B], values in [0,n_types)) also
+ * total_by_type[t] += 1 and correct_by_type[t] += hit.  Counters are int64 and are ADDED to (zero them first). */
+int qt_eval_counts(void* stream, const float* logits, long ld, int B, int C, const long long* label,
+                   const int* qtype, int n_types, long long* predicted,
+                   long long* totals, long long* correct_by_type, long long* total_by_type);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
-SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip']
+SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip']
 GFX = 'gfx950'
 
 
@@ -51,6 +51,10 @@ SIGNATURES = {
     'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_xattn_bwd': [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p],
     'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],
+    'qt_attn_causal_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _f],
+    'qt_text_embed_fwd': [_p, _p, _i, _i, _i, _i, _p, _p, _p],
+    'qt_text_eot_rows': [_p, _p, _i, _i, _i, _p, _p, _p],
+    'qt_eval_counts': [_p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p],
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
                     _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],

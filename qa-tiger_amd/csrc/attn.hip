@@ -37,6 +37,7 @@ struct AttnArgs {
     float* lse;              // [n_items, H, Lq]  log-sum-exp of the scaled scores (written by fwd, read by bwd)
     const float* o_fwd;      // forward output, same addressing as d_o (bwd: delta = rowsum(dO * O))
     float* delta;            // [n_items, H, Lq] workspace
+    int causal;              // forward only: key j visible to query i iff j <= i (CLIP text tower)
 };
 
 __device__ inline int lds_pad(int dh) { return dh + 1; }   // odd row stride: conflict-free column walks
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(NT) void qt_attn_fwd_kernel(AttnArgs p) {
         const float* kr = Ks + j * dp;
         float s = 0.f;
         for (int c = 0; c < dh; ++c) s = fmaf(qr[c], kr[c], s);
-        S[i * sp + j] = s;
+        S[i * sp + j] = (p.causal && j > i) ? -INFINITY : s;
     }
     __syncthreads();
 
@@ -949,11 +950,11 @@ static int attn_block(int Lq, int Lk, int dh) {
     return work <= 14L * 14 * 128 ? 64 : 256;
 }
 
-extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
-                           const float* k, long ldk, const float* v, long ldv, long kv_is,
-                           float* o, long ldo, long o_is, long o_rs,
-                           int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
-                           float scale, float drop_p, unsigned long long seed, float* lse) {
+static int attn_fwd_impl(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                         const float* k, long ldk, const float* v, long ldv, long kv_is,
+                         float* o, long ldo, long o_is, long o_rs,
+                         int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                         float scale, float drop_p, unsigned long long seed, float* lse, int causal) {
     QT_CHECK_ARG(q && k && v && o, "qt_attn_fwd: null pointer");
     QT_CHECK_ARG(n_items > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dh > 0, "qt_attn_fwd: bad sizes");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_attn_fwd: drop_p=%f", drop_p);
@@ -961,13 +962,13 @@ extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, lo
     a.q = q; a.ldq = ldq; a.q_is = q_is; a.q_rs = q_rs; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.kv_is = kv_is;
     a.o = o; a.ldo = ldo; a.o_is = o_is; a.o_rs = o_rs;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
-    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.lse = lse;
-    if (attn_mfma_ok(a, false)) {
+    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.lse = lse; a.causal = causal;
+    if (!causal && attn_mfma_ok(a, false)) {
         int rc;
         QT_ATTN_DISPATCH(launch_fwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return QT_OK; }
     }
-    if (attn_stream_ok(a, false)) {                                  // long sequences: stream K/V with an online softmax
+    if (!causal && attn_stream_ok(a, false)) {                       // long sequences: stream K/V with an online softmax
         int rc;
         QT_ATTN_STREAM_DISPATCH(launch_fwd_stream, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(stream)"); return QT_OK; }
@@ -989,6 +990,25 @@ extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, lo
     }
     QT_CHECK_LAUNCH("qt_attn_fwd");
     return QT_OK;
+}
+
+extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                           const float* k, long ldk, const float* v, long ldv, long kv_is,
+                           float* o, long ldo, long o_is, long o_rs,
+                           int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                           float scale, float drop_p, unsigned long long seed, float* lse) {
+    return attn_fwd_impl(stream, q, ldq, q_is, q_rs, k, ldk, v, ldv, kv_is, o, ldo, o_is, o_rs,
+                         n_items, n_kv, kv_shift, H, Lq, Lk, dh, scale, drop_p, seed, lse, 0);
+}
+
+// Causal self-attention, forward only: the frozen CLIP text tower (reference
+// src/models/base/clip_base.py:211-214 with the additive -inf mask of :390-396).
+extern "C" int qt_attn_causal_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                                  const float* k, long ldk, const float* v, long ldv, long kv_is,
+                                  float* o, long ldo, long o_is, long o_rs,
+                                  int n_items, int H, int L, int dh, float scale) {
+    return attn_fwd_impl(stream, q, ldq, q_is, q_rs, k, ldk, v, ldv, kv_is, o, ldo, o_is, o_rs,
+                         n_items, n_items, 0, H, L, L, dh, scale, 0.f, 0ull, nullptr, 1);
 }
 
 extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, long q_rs,

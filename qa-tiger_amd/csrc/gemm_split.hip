@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     auto epilogue = [&](auto ADD, auto FULL) {
         constexpr bool has_add = decltype(ADD)::value, full = decltype(FULL)::value;
         const bool atomic = p.split_k > 1;
-        const bool do_relu = p.relu != 0;
+        const int act = p.relu;                                     // 0 none, 1 ReLU, 2 QuickGELU x*sigmoid(1.702x)
         const bool use_add = has_add && (!atomic || first_split);
         int ncl[WNT];                                               // clamped columns: loads below need no branches
 #pragma unroll
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                                 float v = p.alpha * acc[i][j][e] + bias_v[j];
                                 if (has_add) v += addv[e8][j];
                                 if (atomic) { atomicAdd(crow + j * 32, v); return; }
-                                if (do_relu) v = fmaxf(v, 0.f);
+                                if (act == 1) v = fmaxf(v, 0.f);
+                                else if (act == 2) v = v / (1.0f + __expf(-1.702f * v));
                                 if constexpr (full) {
                                     if (p.mask_src) v = (mskv[e8][j] > 0.f) ? v * p.mask_scale : 0.f;
                                     if (p.drop_p > 0.f)

@@ -52,6 +52,14 @@ def _dev(*ts: Optional[Tensor]) -> None:
             raise _lib.QTError(f'fp32 tensor expected, got {t.dtype}')
 
 
+def _on_gpu(*ts: Optional[Tensor]) -> None:
+    """Device check for integer operands (token ids, labels, question types)."""
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.QTError('qa-tiger_amd kernels need tensors on an MI355X (cuda) device; got a '
+                               f'{t.device.type} tensor and there is no CPU fallback')
+
+
 def as2d(t: Tensor) -> Tensor:
     """View as [rows, cols] with unit column stride (copy only if unavoidable)."""
     if t.dim() != 2:
@@ -642,3 +650,79 @@ def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor,
     rc = _lib.load().qt_adam_step(_stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step),
                                   float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale))
     _lib.check(rc, 'qt_adam_step')
+
+
+# --------------------------------------------------------------------------- #
+# frozen text tower + evaluation counters (csrc/text.hip) — forward only
+# --------------------------------------------------------------------------- #
+def text_embed(text: Tensor, token_embedding: Tensor, positional_embedding: Tensor) -> Tensor:
+    """x[b,l,:] = token_embedding[text[b,l]] + positional_embedding[l]  (reference encoders.py:31-32)."""
+    _on_gpu(text)
+    _dev(token_embedding, positional_embedding)
+    if text.dtype != torch.int32:
+        text = text.to(torch.int32)
+    text = text.contiguous()
+    B, L = text.shape
+    vocab, W = token_embedding.shape
+    if L > positional_embedding.shape[0]:
+        raise _lib.QTError(f'text_embed: {L} tokens but only {positional_embedding.shape[0]} positions')
+    out = torch.empty((B, L, W), device=text.device, dtype=torch.float32)
+    _lib.check(_lib.load().qt_text_embed_fwd(_stream(), _ptr(text), B, L, W, vocab, _ptr(token_embedding.contiguous()),
+                                             _ptr(positional_embedding.contiguous()), _ptr(out)), 'qt_text_embed_fwd')
+    return out
+
+
+def text_eot_rows(text: Tensor, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """x[b, argmax_l text[b,l], :] and the chosen positions (reference encoders.py:37)."""
+    _on_gpu(text)
+    _dev(x)
+    if text.dtype != torch.int32:
+        text = text.to(torch.int32)
+    text = text.contiguous()
+    B, L = text.shape
+    x = x.contiguous()
+    W = x.shape[-1]
+    out = torch.empty((B, W), device=x.device, dtype=torch.float32)
+    idx = torch.empty((B,), device=x.device, dtype=torch.int32)
+    _lib.check(_lib.load().qt_text_eot_rows(_stream(), _ptr(text), B, L, W, _ptr(x), _ptr(out), _ptr(idx)), 'qt_text_eot_rows')
+    return out, idx
+
+
+def causal_attention(qkv: Tensor, n_items: int, L: int, H: int) -> Tensor:
+    """Causal self-attention on packed QKV rows [n_items*L, 3E] (item-major) -> [n_items*L, E]."""
+    qkv = as2d(qkv)
+    _dev(qkv)
+    E = qkv.shape[1] // 3
+    dh = E // H
+    o = torch.empty((n_items * L, E), device=qkv.device, dtype=torch.float32)
+    f4 = 4
+    rc = _launch('attn_fwd', 4.0 * E * 4 * n_items * L, ('causal', n_items, L, L, E), lambda: _lib.load().qt_attn_causal_fwd(
+        _stream(), _ptr(qkv), _ld(qkv), L, 1,
+        C.c_void_p(qkv.data_ptr() + E * f4), _ld(qkv), C.c_void_p(qkv.data_ptr() + 2 * E * f4), _ld(qkv), L,
+        _ptr(o), E, L, 1, n_items, H, L, dh, 1.0 / math.sqrt(dh)))
+    _lib.check(rc, 'qt_attn_causal_fwd')
+    return o
+
+
+def eval_counts(logits: Tensor, label: Tensor, qtype: Optional[Tensor] = None, n_types: int = 9,
+                totals: Optional[Tensor] = None, correct_by_type: Optional[Tensor] = None,
+                total_by_type: Optional[Tensor] = None):
+    """Device-side argmax + accuracy counters (reference trainutils.py:338-346, 417-423).
+
+    Returns (predicted [B] int64, totals [2] int64 = (samples, correct), correct_by_type [n_types], total_by_type [n_types]);
+    pass the three counter tensors back in to keep accumulating over batches without a host sync."""
+    _on_gpu(label, qtype)
+    _dev(logits)
+    logits = as2d(logits)
+    B, Cn = logits.shape
+    dev = logits.device
+    label = label.to(torch.int64).contiguous()
+    if qtype is not None:
+        qtype = qtype.to(torch.int32).contiguous()
+    totals = torch.zeros(2, dtype=torch.int64, device=dev) if totals is None else totals
+    correct_by_type = torch.zeros(n_types, dtype=torch.int64, device=dev) if correct_by_type is None else correct_by_type
+    total_by_type = torch.zeros(n_types, dtype=torch.int64, device=dev) if total_by_type is None else total_by_type
+    pred = torch.empty(B, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().qt_eval_counts(_stream(), _ptr(logits), _ld(logits), B, Cn, _ptr(label), _ptr(qtype), n_types,
+                                          _ptr(pred), _ptr(totals), _ptr(correct_by_type), _ptr(total_by_type)), 'qt_eval_counts')
+    return pred, totals, correct_by_type, total_by_type

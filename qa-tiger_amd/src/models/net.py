@@ -35,7 +35,7 @@ CLIP_TEncoder = _enc.CLIP_TEncoder
 class QA_TIGER(nn.Module):
     def __init__(self, d_model: int = 512, video_dim: int = 512, patch_dim: int = 768, audio_dim: int = 128,
                  topK: int = 3, num_experts: int = 10, late_fusion: bool = False, nce_loss: bool = False,
-                 encoder_type: str = 'ViT-L/14@336px', **kwargs):
+                 encoder_type: str = 'ViT-L/14@336px', text_tower=None, **kwargs):
         super().__init__()
         self.nce_loss = nce_loss
         self.late_fusion = late_fusion
@@ -44,7 +44,7 @@ class QA_TIGER(nn.Module):
         self.patch_proj = Projection(patch_dim, d_model)
         self.words_proj = Projection(video_dim, d_model)
         self.quest_proj = Projection(video_dim, d_model)
-        self.quest_encoder = CLIP_TEncoder(encoder_type)
+        self.quest_encoder = CLIP_TEncoder(encoder_type, tower=text_tower)   # text_tower: None (features are handed in) | 'vitl14' | TextConfig
         self.quest_encoder.freeze()
         self.crs_attn = AVQCrossAttn(d_model, 8)
         self.patch_selecter = PatchSelecter(d_model, 8)

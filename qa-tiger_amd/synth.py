@@ -183,3 +183,96 @@ def fast_device_inputs(cfg: PathConfig, device, seed: int = 713) -> Dict[str, to
         words_feat=rn(cfg.B, cfg.L, cfg.Dv),
         label=torch.randint(0, cfg.A, (cfg.B,), generator=g, device=device),
     )
+
+
+# --------------------------------------------------------------------------- #
+# frozen CLIP text tower: shapes, recipe weights, token batches
+# --------------------------------------------------------------------------- #
+@dataclass(frozen=True)
+class TextConfig:
+    """Text-transformer hyper-parameters as `build_model` derives them from a CLIP
+    checkpoint (reference src/models/base/clip_base.py:479-484)."""
+    width: int = 768
+    layers: int = 12
+    heads: int = 12           # width // 64
+    context_length: int = 77
+    vocab_size: int = 49408
+    embed_dim: int = 768      # text_projection output = QA_TIGER's video_dim
+
+    def asdict(self):
+        return dict(width=self.width, layers=self.layers, heads=self.heads, context_length=self.context_length,
+                    vocab_size=self.vocab_size, embed_dim=self.embed_dim)
+
+
+TEXT_VITL14 = TextConfig()                                           # ViT-L/14@336px text side
+TEXT_TOY = TextConfig(width=128, layers=2, heads=2, context_length=77, vocab_size=512, embed_dim=96)
+
+
+def text_param_shapes(cfg: TextConfig) -> Dict[str, tuple]:
+    """state_dict names of the reference `CLIP_TEncoder` (encoders.py:14-22) -> shapes."""
+    W = cfg.width
+    s: Dict[str, tuple] = {'token_embedding.weight': (cfg.vocab_size, W),
+                           'positional_embedding': (cfg.context_length, W)}
+    for i in range(cfg.layers):
+        p = f'transformer.resblocks.{i}.'
+        s[p + 'attn.in_proj_weight'] = (3 * W, W)
+        s[p + 'attn.in_proj_bias'] = (3 * W,)
+        s[p + 'attn.out_proj.weight'] = (W, W)
+        s[p + 'attn.out_proj.bias'] = (W,)
+        s[p + 'ln_1.weight'] = (W,)
+        s[p + 'ln_1.bias'] = (W,)
+        s[p + 'mlp.c_fc.weight'] = (4 * W, W)
+        s[p + 'mlp.c_fc.bias'] = (4 * W,)
+        s[p + 'mlp.c_proj.weight'] = (W, 4 * W)
+        s[p + 'mlp.c_proj.bias'] = (W,)
+        s[p + 'ln_2.weight'] = (W,)
+        s[p + 'ln_2.bias'] = (W,)
+    s['ln_final.weight'] = (W,)
+    s['ln_final.bias'] = (W,)
+    s['text_projection'] = (W, cfg.embed_dim)
+    s['logit_scale'] = ()
+    return s
+
+
+def make_text_state_dict(cfg: TextConfig, seed: int = 713) -> Dict[str, torch.Tensor]:
+    """Recipe weights for the text tower: the scales of `CLIP.initialize_parameters`
+    (clip_base.py:361-388) with non-trivial biases and LayerNorm gains, name-seeded."""
+    W = cfg.width
+    proj_std = (W ** -0.5) * ((2 * cfg.layers) ** -0.5)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in text_param_shapes(cfg).items():
+        if name == 'logit_scale':
+            out[name] = torch.tensor(float(np.log(1 / 0.07)), dtype=torch.float32)
+            continue
+        z = _normal('text.' + name, shape, seed)
+        leaf = name.split('.')[-1]
+        if name == 'token_embedding.weight':
+            w = np.float32(0.02) * z
+        elif name == 'positional_embedding':
+            w = np.float32(0.01) * z
+        elif name == 'text_projection' or leaf == 'in_proj_weight':
+            w = np.float32(W ** -0.5) * z
+        elif name.endswith('out_proj.weight') or name.endswith('c_proj.weight'):
+            w = np.float32(proj_std) * z
+        elif name.endswith('c_fc.weight'):
+            w = np.float32((2 * W) ** -0.5) * z
+        elif '.ln_' in name or name.startswith('ln_final'):
+            w = (np.float32(1.0) + np.float32(0.1) * z) if leaf == 'weight' else np.float32(0.05) * z
+        else:                                                          # Linear / in_proj biases
+            w = np.float32(0.02) * z
+        out[name] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+    return out
+
+
+def make_text_tokens(cfg: TextConfig, B: int, seed: int = 713) -> torch.Tensor:
+    """int32 [B, context_length] batches shaped like CLIP's tokenizer output: start token,
+    3..30 word-piece ids, end token (the largest id, so argmax finds it), zero padding."""
+    rng = np.random.Generator(np.random.PCG64(_seed('text.tokens', seed)))
+    sot, eot = cfg.vocab_size - 2, cfg.vocab_size - 1
+    out = np.zeros((B, cfg.context_length), dtype=np.int32)
+    for b in range(B):
+        n = int(rng.integers(3, min(31, cfg.context_length - 2)))
+        out[b, 0] = sot
+        out[b, 1:1 + n] = rng.integers(1, cfg.vocab_size - 2, size=n)
+        out[b, 1 + n] = eot
+    return torch.from_numpy(out)

@@ -1,0 +1,125 @@
+"""Frozen CLIP text tower and evaluation counters on the HIP kernels,
+through the nn.Module surface and the C ABI.  GPU box only.
+
+Pins: golden vectors produced by the reference's own clip_base modules (tests/golden/text_*.npz,
+tools/make_golden.py) and the CPU oracle (oracle/clip_text_oracle.py) on other seeded batches.
+Tolerance: the tower is fp32 with 3xfp16 split GEMM products (~2e-6 per GEMM); 12 layers land near
+1e-5, asserted < 1e-4 relative to max|feature| (the path's logit gate is 1e-3)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+EXPECT = 1e-4
+
+
+def tower(qt, synth, cfg, seed):
+    enc = importlib.import_module('qa-tiger_amd.src.models.encoders').CLIP_TEncoder('ViT-L/14@336px', tower=cfg)
+    enc.load_state_dict(synth.make_text_state_dict(cfg, seed), strict=True)
+    enc.freeze()
+    return enc.to(DEV).eval()
+
+
+@pytest.mark.parametrize('name,attr', [('text_toy', 'TEXT_TOY'), ('text_vitl14_b4', 'TEXT_VITL14')])
+def test_text_tower_matches_reference_golden(qt, synth, name, attr):
+    g = load_golden(name)
+    cfg = getattr(synth, attr)
+    enc = tower(qt, synth, cfg, int(g['seed']))
+    text = torch.from_numpy(g['text']).to(DEV)
+    quest, words = enc(text)
+    assert quest.shape == (text.shape[0], cfg.embed_dim) and words.shape == (text.shape[0], cfg.context_length, cfg.width)
+    assert rel_err(quest.cpu().numpy(), g['quest']) < EXPECT
+    w = words.cpu().numpy()
+    if 'words' in g:
+        assert rel_err(w, g['words']) < EXPECT
+    else:
+        assert rel_err(w.reshape(-1)[:: max(1, w.size // 8192)][:8192], g['words_slice']) < EXPECT
+        assert rel_err(w[np.arange(w.shape[0]), g['text'].argmax(-1)], g['words_eot']) < EXPECT
+
+
+def test_text_tower_matches_oracle_other_batch(qt, synth):
+    text_oracle = importlib.import_module('oracle.clip_text_oracle')
+    cfg = synth.TEXT_TOY
+    P = synth.make_text_state_dict(cfg, 99)
+    text = synth.make_text_tokens(cfg, 33, 99)                      # B not a multiple of the 4-rows-per-block kernels
+    text[7, :] = 0; text[7, 0] = cfg.vocab_size - 1                 # EOT at position 0
+    text[8, -1] = cfg.vocab_size - 1; text[8, 5] = cfg.vocab_size - 1   # duplicate maximum: the first one wins
+    with torch.no_grad():
+        q_ref, w_ref = text_oracle.clip_text_forward(P, text, cfg.heads)
+    enc = tower(qt, synth, cfg, 99)
+    quest, words = enc(text.to(DEV))
+    assert rel_err(quest.cpu().numpy(), q_ref.numpy()) < EXPECT
+    assert rel_err(words.cpu().numpy(), w_ref.numpy()) < EXPECT
+
+
+def test_causal_attention_op(qt):
+    ops = qt.ops
+    g = torch.Generator().manual_seed(3)
+    for (n, L, H, dh) in [(3, 77, 12, 64), (5, 20, 2, 32), (2, 1, 4, 16)]:
+        E = H * dh
+        qkv = torch.randn(n * L, 3 * E, generator=g)
+        o = ops.causal_attention(qkv.to(DEV), n, L, H).cpu()
+        q, k, v = [t.reshape(n, L, H, dh).transpose(1, 2) for t in qkv.split(E, dim=-1)]
+        s = (q @ k.transpose(-1, -2)) / dh ** 0.5 + torch.full((L, L), float('-inf')).triu(1)
+        ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n * L, E)
+        assert rel_err(o.numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'f16x3', 'bf16x3'])
+def test_gemm_quick_gelu_epilogue(qt, mode):
+    ops = qt.ops
+    g = torch.Generator().manual_seed(4)
+    for (M, N, K) in [(300, 512, 128), (77, 96, 64)]:
+        a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+        out = ops.gemm(a.to(DEV), w.to(DEV), bias=b.to(DEV), relu=2, mode=mode).cpu()
+        z = a.double() @ w.double().t() + b.double()
+        ref = (z * torch.sigmoid(1.702 * z)).float()
+        assert rel_err(out.numpy(), ref.numpy()) < (2e-4 if mode == 'bf16x3' else 2e-5)
+
+
+def test_model_runs_from_raw_tokens(qt, synth):
+    """QA_TIGER with the tower built in: int tokens in `quest` give the same logits as handing in the
+    tower's features (reference net.py:98-101 vs the synthetic route)."""
+    # words_proj consumes the tower's token features, so tower width = embed_dim = video_dim (reference net.py:46-47)
+    cfg = synth.PathConfig(**{**synth.CONFIG_TOY.asdict(), 'Dv': 64})
+    tcfg = synth.TextConfig(width=64, layers=2, heads=1, context_length=cfg.L, vocab_size=300, embed_dim=64)
+    model = qt.QA_TIGER(**cfg.model_kwargs(), text_tower=tcfg)
+    sd = synth.make_state_dict(cfg, 21)
+    sd.update({'quest_encoder.' + k: v for k, v in synth.make_text_state_dict(tcfg, 21).items()})
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    inp = {k: v.to(DEV) for k, v in synth.make_inputs(cfg, 21).items()}
+    text = synth.make_text_tokens(tcfg, cfg.B, 21).to(DEV)
+    with torch.no_grad():
+        quest, words = model.quest_encoder(text)
+        a = model(dict(audio=inp['audio'], video=inp['video'], patch=inp['patch'], quest=text))['out']
+        b = model(dict(audio=inp['audio'], video=inp['video'], patch=inp['patch'], quest=None,
+                       quest_feat=quest, words_feat=words))['out']
+    assert torch.allclose(a, b, rtol=0, atol=1e-5 * float(b.abs().max()))
+
+
+def test_eval_counts(qt):
+    ops = qt.ops
+    g = torch.Generator().manual_seed(6)
+    tot = cbt = tbt = None
+    exp_tot, exp_cor = 0, 0
+    exp_c, exp_t = np.zeros(9, np.int64), np.zeros(9, np.int64)
+    for B in (1, 257, 64):
+        logits = torch.randn(B, 42, generator=g)
+        logits[0, 5] = logits[0, 9] = 50.0                           # tie: first maximum wins (torch.max)
+        label = torch.randint(0, 42, (B,), generator=g)
+        label[::3] = logits[::3].argmax(-1)
+        qtype = torch.randint(0, 9, (B,), generator=g)
+        pred, tot, cbt, tbt = ops.eval_counts(logits.to(DEV), label.to(DEV), qtype.to(DEV), 9, tot, cbt, tbt)
+        ref = torch.max(logits, 1)[1]
+        assert torch.equal(pred.cpu(), ref)
+        hit = (ref == label).numpy()
+        exp_tot += B; exp_cor += int(hit.sum())
+        np.add.at(exp_t, qtype.numpy(), 1); np.add.at(exp_c, qtype.numpy(), hit.astype(np.int64))
+    assert tot.cpu().tolist() == [exp_tot, exp_cor]
+    assert np.array_equal(cbt.cpu().numpy(), exp_c) and np.array_equal(tbt.cpu().numpy(), exp_t)

@@ -151,3 +151,44 @@ def test_adam_matches_torch(oracle):
         oracle.adam_step(mine, grads, m, v, step)
         for n in ref:
             assert torch.allclose(mine[n], ref[n].detach(), atol=1e-7, rtol=1e-6)
+
+
+# ---- frozen CLIP text tower: oracle/clip_text_oracle.py vs the reference's clip_base modules ----
+TEXT_GOLDEN = {'text_toy': 'TEXT_TOY', 'text_vitl14_b4': 'TEXT_VITL14'}
+
+
+@pytest.mark.parametrize('name', list(TEXT_GOLDEN))
+def test_text_tower_oracle_matches_reference(synth, name):
+    import importlib
+    text_oracle = importlib.import_module('oracle.clip_text_oracle')
+    g = load_golden(name)
+    cfg = getattr(synth, TEXT_GOLDEN[name])
+    assert list(cfg.asdict().values()) == g['cfg'].tolist()
+    P = synth.make_text_state_dict(cfg, int(g['seed']))
+    assert sum(float(v.double().abs().sum()) for v in P.values()) == pytest.approx(float(g['weights_checksum']), rel=1e-12)
+    text = synth.make_text_tokens(cfg, int(g['B']), int(g['seed']))
+    assert np.array_equal(text.numpy(), g['text'])
+    with torch.no_grad():
+        quest, words = text_oracle.clip_text_forward(P, text, cfg.heads)
+    assert rel_err(quest.numpy(), g['quest']) < TOL
+    w = words.numpy()
+    if 'words' in g:
+        assert rel_err(w, g['words']) < TOL
+    else:
+        assert rel_err(w.reshape(-1)[:: max(1, w.size // 8192)][:8192], g['words_slice']) < TOL
+        assert rel_err(w[np.arange(w.shape[0]), g['text'].argmax(-1)], g['words_eot']) < TOL
+        assert np.allclose([w.mean(), np.abs(w).mean(), w.std()], g['words_sum'], rtol=1e-5, atol=1e-7)
+
+
+def test_text_tower_is_causal(synth):
+    """Changing a token must not change the features of earlier positions (clip_base.py:390-396)."""
+    import importlib
+    text_oracle = importlib.import_module('oracle.clip_text_oracle')
+    cfg = synth.TEXT_TOY
+    P = synth.make_text_state_dict(cfg, 5)
+    text = synth.make_text_tokens(cfg, 2, 5)
+    t2 = text.clone(); t2[:, 4] = (t2[:, 4] + 7) % (cfg.vocab_size - 2)
+    with torch.no_grad():
+        _, w1 = text_oracle.clip_text_forward(P, text, cfg.heads)
+        _, w2 = text_oracle.clip_text_forward(P, t2, cfg.heads)
+    assert torch.equal(w1[:, :4], w2[:, :4]) and not torch.allclose(w1[:, 4:], w2[:, 4:])

@@ -185,10 +185,55 @@ def block_kats(modules):
     return rec
 
 
+def text_golden(text_cfg, B, seed, full):
+    """Run the reference's own text-side CLIP modules (src/models/base/clip_base.py, pure torch) in the
+    order `CLIP_TEncoder.forward` calls them (src/models/encoders.py:30-37; that file itself imports the
+    checkpoint downloader and PIL/torchvision, so it cannot be imported here)."""
+    clip_base = importlib.import_module('src.models.base.clip_base')
+    torch.manual_seed(0)
+    model = clip_base.CLIP(q_aware_N=-1, embed_dim=text_cfg.embed_dim,
+                           image_resolution=32, vision_layers=1, vision_width=64, vision_patch_size=16,   # unused vision side, kept tiny
+                           context_length=text_cfg.context_length, vocab_size=text_cfg.vocab_size,
+                           transformer_width=text_cfg.width, transformer_heads=text_cfg.heads,
+                           transformer_layers=text_cfg.layers).float().eval()
+    sd = synth.make_text_state_dict(text_cfg, seed)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    assert all(k.startswith('visual.') for k in msg.missing_keys), msg.missing_keys
+    text = synth.make_text_tokens(text_cfg, B, seed)
+    with torch.no_grad():
+        x = model.token_embedding(text).type(model.dtype)
+        x = x + model.positional_embedding.type(model.dtype)[:x.shape[1]]
+        x = x.permute(1, 0, 2)
+        x = model.transformer(x)
+        x = x.permute(1, 0, 2)
+        x = model.ln_final(x).type(model.dtype)
+        quest = x[torch.arange(x.shape[0]), torch.argmax(text, dim=-1)] @ model.text_projection
+    rec = {'cfg': np.array(list(text_cfg.asdict().values()), dtype=np.int64), 'seed': np.int64(seed), 'B': np.int64(B),
+           'text': text.numpy(), 'quest': quest.numpy(),
+           'weights_checksum': np.float64(sum(float(v.double().abs().sum()) for v in sd.values()))}
+    w = x.numpy()
+    if full:
+        rec['words'] = w
+    else:
+        rec['words_sum'] = np.array([w.mean(), np.abs(w).mean(), w.std()], dtype=np.float64)
+        rec['words_slice'] = w.reshape(-1)[:: max(1, w.size // 8192)][:8192].copy()
+        rec['words_eot'] = w[np.arange(B), text.numpy().argmax(-1)]
+    return rec
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     net, modules = import_reference()
+    if '--text-only' in sys.argv or '--all' in sys.argv or len(sys.argv) == 1:
+        for name, tcfg, B, full in [('text_toy', synth.TEXT_TOY, 5, True), ('text_vitl14_b4', synth.TEXT_VITL14, 4, False)]:
+            rec = text_golden(tcfg, B, 713, full)
+            path = os.path.join(OUT, f'{name}.npz')
+            np.savez_compressed(path, **rec)
+            print(f'{name}: |quest|max={np.abs(rec["quest"]).max():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB')
+        if '--text-only' in sys.argv:
+            return
     np.savez_compressed(os.path.join(OUT, 'tempmoe_kats.npz'), **block_kats(modules))
     jobs = [('toy', synth.CONFIG_TOY, 713, 'all'),
             ('toy_kk', synth.CONFIG_TOY_KK, 11, 'all'),
