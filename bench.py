@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16, help='batch of the bounded CPU-baseline sample')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
+    ap.add_argument('--reduced-precision', action='store_true', help='also time the bf16x1 GEMM mode (BASELINE config 5 direction: one bf16 MFMA per product); reported beside the metric with its arg-max agreement, never as the metric')
+    ap.add_argument('--text-tower', action='store_true', help='also time the frozen CLIP text tower (ViT-L/14 text side, forward, B x 77 tokens); reported beside the metric, never in it')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra instrumented steps for the roofline (after the timed region)')
     return ap.parse_args()
 
@@ -184,6 +186,64 @@ def main():
                              algorithmic_mb_per_sample=round(a_bytes / cfg.B / 1e6, 2), ms_per_step=round(a_ms, 3),
                              share_of_step=round(a_ms / ms_step, 3))
 
+    reduced = None
+    if args.reduced_precision and world == 1:
+        keep = dict(ops.precision)
+        model.eval()
+        with torch.no_grad():
+            ref_logits = model(batch)['out'].clone()
+        ops.precision.update(fwd='bf16x1', bwd='bf16x1')
+        try:
+            with torch.no_grad():
+                low_logits = model(batch)['out'].clone()
+                for _ in range(2):
+                    model(batch)
+                sync()
+                t3 = time.perf_counter()
+                for _ in range(n_fwd):
+                    model(batch)
+                sync()
+                low_fwd = per_gpu * n_fwd / (time.perf_counter() - t3)
+            model.train()
+            for _ in range(2):
+                eng.step(batch)
+            sync()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.step(batch)
+            sync()
+            low_dt = (time.perf_counter() - t3) / args.steps
+        finally:
+            ops.precision.update(keep)
+            model.train()
+        reduced = dict(mode='bf16x1 (operands rounded to bf16, one MFMA per product, fp32 accumulate)',
+                       value=round(per_gpu / low_dt, 1), unit='QA-pairs/s', ms_per_step=round(low_dt * 1e3, 3),
+                       fwd_only=round(low_fwd, 1),
+                       argmax_agreement=round(float((ref_logits.argmax(-1) == low_logits.argmax(-1)).float().mean()), 4),
+                       max_rel_logit_diff=round(float((ref_logits - low_logits).abs().max() / ref_logits.abs().max()), 5),
+                       note='outside the 1e-3 parity gate; not the benchmarked metric')
+
+    text_tower = None
+    if args.text_tower and rank == 0:
+        # on the real (non-synthetic) path this runs once per batch in front of the fusion model
+        enc = importlib.import_module('qa-tiger_amd.src.models.encoders').CLIP_TEncoder('ViT-L/14@336px', tower='vitl14').to(dev).eval()
+        tokens = synth.make_text_tokens(synth.TEXT_VITL14, per_gpu, 713).to(dev)
+        for _ in range(2):
+            enc(tokens)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n_txt = max(3, args.steps)
+        for _ in range(n_txt):
+            enc(tokens)
+        torch.cuda.synchronize()
+        txt_dt = (time.perf_counter() - t2) / n_txt
+        tc = synth.TEXT_VITL14
+        gflop = (tc.layers * (2 * tc.context_length * 12 * tc.width ** 2 + 4 * tc.context_length ** 2 * tc.width) + 2 * tc.width * tc.embed_dim) / 1e9
+        text_tower = dict(value=round(per_gpu / txt_dt, 1), unit='questions/s', ms_per_batch=round(txt_dt * 1e3, 3), batch=per_gpu,
+                          tokens=tc.context_length, gflop_per_question=round(gflop, 3),
+                          algorithmic_tflops=round(per_gpu / txt_dt * gflop / 1e3, 1), weights='random (CLIP initialiser scales); no checkpoint offline')
+        del enc
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(qt, args.cpu_sample)
@@ -204,6 +264,10 @@ def main():
             'loss': round(float(loss), 5),
             'roofline': roofline, 'attention': attention, 'cpu_baseline': cpu,
         }
+        if text_tower is not None:
+            out['text_tower'] = text_tower
+        if reduced is not None:
+            out['reduced_precision'] = reduced
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -49,7 +49,8 @@ int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float
 
 /* Same contract as qt_gemm_f32, computed with three 16-bit MFMAs per product on operands split
  * on the fly into hi+lo parts (half_type 0: fp16 parts, ~fp32-accurate, operands must be inside
- * fp16 range — forward GEMMs; 1: bf16 parts, ~1.5e-5 relative, full exponent range — backward GEMMs).
+ * fp16 range — forward GEMMs; 1: bf16 parts, ~1.5e-5 relative, full exponent range — backward GEMMs;
+ * 3: ONE bf16 product per term, ~4e-3 relative — the reduced-precision mode of BASELINE config 5, never the parity path).
  * a_colsum (nullable, transA only): a_colsum[m] = sum_k A[k,m] — the bias gradient of a Linear layer
  * computed while the dW GEMM streams dY (A = dY given as [rows, N_out]).
  * Returns -4 without touching C or a_colsum when the shape or alignment does not fit its tiles;

@@ -31,13 +31,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
             os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', f'--offload-arch={GFX}', '-fPIC', '-shared', '-std=c++17',
-           '-Wno-unused-result', '-o', LIB_PATH] + srcs
-    if verbose:
-        print(' '.join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    flags = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
+    objdir = os.path.join(CSRC, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    # one object per translation unit, compiled in parallel; gemm_split.hip is built in parts (see its tail)
+    jobs = []
+    for src in srcs:
+        base = os.path.splitext(os.path.basename(src))[0]
+        parts = range(7) if base == 'gemm_split' else [None]
+        for part in parts:
+            obj = os.path.join(objdir, base + ('' if part is None else f'_p{part}') + '.o')
+            jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-DQT_X3_PART={part}']), obj))
+
+    def run(job):
+        cmd, _ = job
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        return subprocess.run(cmd, capture_output=True, text=True)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
+        results = list(pool.map(run, jobs))
+    for (cmd, _), res in zip(jobs, results):
+        if res.returncode != 0:
+            raise QTError(f'hipcc failed: {" ".join(cmd)}\n{res.stdout}\n{res.stderr}')
+    link = [hipcc, f'--offload-arch={GFX}', '-fPIC', '-shared', '-o', LIB_PATH] + [obj for _, obj in jobs]
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise QTError(f'hipcc failed:\n{res.stdout}\n{res.stderr}')
+        raise QTError(f'hipcc link failed:\n{res.stdout}\n{res.stderr}')
     return LIB_PATH
 
 

@@ -12,6 +12,7 @@
 //   HT = 0  fp16 parts: 11+11 significand bits -> ~fp32-accurate products.  Used
 //           for forward GEMMs (activations/weights are O(1e-3..1e1), inside
 //           fp16 range; fp16 subnormals are honoured by the MFMA).
+//   HT = 3  bf16 hi parts only (one MFMA per product): the reduced-precision mode, not used by the parity path.
 //   HT = 1  bf16 parts: 8+8 bits (~1.5e-5 relative) with the full fp32 exponent
 //           range.  Used for backward GEMMs whose operands are gradients
 //           (down to 1e-9) that fp16 cannot hold.
@@ -67,7 +68,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // parts: 5 VALU instructions per pair.
 template <int HT> __device__ inline void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     const f32x2 x = {x0, x1};
-    if (HT == 0) {
+    if ((HT & 1) == 0) {
         const f16x2 h = __builtin_convertvector(x, f16x2);
         const f32x2 d = x - __builtin_convertvector(h, f32x2);
         hi = __builtin_bit_cast(unsigned, h);
@@ -97,7 +98,7 @@ template <class F, int... Is> __device__ inline void static_for_impl(F&& f, std:
 template <int N, class F> __device__ inline void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int HT> __device__ inline floatx16 mma(const uint4& a, const uint4& b, floatx16 c) {
-    if (HT == 0) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if ((HT & 1) == 0) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             split_pair<HT>(src[it * 4 + 0], src[it * 4 + 1], vh.x, vl.x);
             split_pair<HT>(src[it * 4 + 2], src[it * 4 + 3], vh.y, vl.y);
             *reinterpret_cast<uint2*>(hi_img + row * SLD + kq * 4) = vh;
-            *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
+            if constexpr (HT < 2) *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
         }
     };
     float csum = 0.f;                                               // this thread's share of a_colsum (TA only)
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             split_pair<HT>(src[e * 8 + 4], src[e * 8 + 5], vh.z, vl.z);
             split_pair<HT>(src[e * 8 + 6], src[e * 8 + 7], vh.w, vl.w);
             *reinterpret_cast<uint4*>(hi_img + col * SLD + kb + e * 8) = vh;
-            *reinterpret_cast<uint4*>(lo_img + col * SLD + kb + e * 8) = vl;
+            if constexpr (HT < 2) *reinterpret_cast<uint4*>(lo_img + col * SLD + kb + e * 8) = vl;
         }
     };
     auto gload = [&](int k0, auto& xa, auto& xb) {
@@ -270,20 +271,22 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             for (int i = 0; i < WMT; ++i) {
                 const int off = (wm * (WMT * 32) + i * 32 + r) * SLD + s * 16 + h * 8;
                 ah[i] = *reinterpret_cast<const uint4*>(sAh + off);
-                al[i] = *reinterpret_cast<const uint4*>(sAl + off);
+                if constexpr (HT < 2) al[i] = *reinterpret_cast<const uint4*>(sAl + off);
             }
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
                 const int off = (wn * (WNT * 32) + j * 32 + r) * SLD + s * 16 + h * 8;
                 bh[j] = *reinterpret_cast<const uint4*>(sBh + off);
-                bl[j] = *reinterpret_cast<const uint4*>(sBl + off);
+                if constexpr (HT < 2) bl[j] = *reinterpret_cast<const uint4*>(sBl + off);
             }
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int j = 0; j < WNT; ++j) {
-                    acc[i][j] = mma<HT>(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = mma<HT>(ah[i], bl[j], acc[i][j]);
+                    if constexpr (HT < 2) {
+                        acc[i][j] = mma<HT>(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = mma<HT>(ah[i], bl[j], acc[i][j]);
+                    }
                     acc[i][j] = mma<HT>(ah[i], bh[j], acc[i][j]);
                 }
         }
@@ -462,9 +465,33 @@ static void launch_x3(const GemmArgs& a, int transA, int transB, dim3 grid, hipS
 #undef QT_X3
 }
 
+// This file is compiled seven times (qa-tiger_amd/_lib.py): -DQT_X3_PART=1..6 each instantiate the four
+// transpose variants of ONE (tile, half type) pair, part 0 holds the C entry point.  The parts build in
+// parallel; one translation unit with all 24 kernels took six minutes.
+#ifndef QT_X3_PART
+#define QT_X3_PART 0
+#endif
+#define QT_X3_DECL(NAME) void NAME(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t st)
+QT_X3_DECL(qt_x3_big_0); QT_X3_DECL(qt_x3_big_1); QT_X3_DECL(qt_x3_big_3);
+QT_X3_DECL(qt_x3_small_0); QT_X3_DECL(qt_x3_small_1); QT_X3_DECL(qt_x3_small_3);
+#if QT_X3_PART == 1
+QT_X3_DECL(qt_x3_big_0) { launch_x3<4, 2, 2, 4, 1, 0>(a, transA, transB, grid, st); }
+#elif QT_X3_PART == 2
+QT_X3_DECL(qt_x3_big_1) { launch_x3<4, 2, 2, 4, 1, 1>(a, transA, transB, grid, st); }
+#elif QT_X3_PART == 3
+QT_X3_DECL(qt_x3_big_3) { launch_x3<4, 2, 2, 4, 1, 3>(a, transA, transB, grid, st); }
+#elif QT_X3_PART == 4
+QT_X3_DECL(qt_x3_small_0) { launch_x3<2, 2, 2, 2, 2, 0>(a, transA, transB, grid, st); }
+#elif QT_X3_PART == 5
+QT_X3_DECL(qt_x3_small_1) { launch_x3<2, 2, 2, 2, 2, 1>(a, transA, transB, grid, st); }
+#elif QT_X3_PART == 6
+QT_X3_DECL(qt_x3_small_3) { launch_x3<2, 2, 2, 2, 2, 3>(a, transA, transB, grid, st); }
+#else
+
 // Returns QT_ERR_UNSUPPORTED (without touching C) when the shape/alignment does not fit
 // this kernel; the caller then uses qt_gemm_f32.
-// half_type: 0 fp16 parts, 1 bf16 parts; +16 forces the 128x128 tile, +32 forces the 256x256 tile (A/B testing).
+// half_type: 0 fp16 parts x3, 1 bf16 parts x3, 3 = ONE bf16 product per term (reduced precision, BASELINE config 5's
+// 16-bit mode: operands rounded to bf16, fp32 accumulate); +16 forces the 128x128 tile, +32 forces the 256x256 tile (A/B testing).
 extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N, int K, float alpha,
                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                           const float* bias, const float* add_src, long ld_add, int relu,
@@ -478,7 +505,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     QT_CHECK_ARG(batch <= 65535, "qt_gemm_x3: batch too large");
     const int force = half_type >> 4;
     half_type &= 15;
-    QT_CHECK_ARG(half_type == 0 || half_type == 1, "qt_gemm_x3: half_type must be 0 (fp16) or 1 (bf16)");
+    QT_CHECK_ARG(half_type == 0 || half_type == 1 || half_type == 3, "qt_gemm_x3: half_type must be 0 (3x fp16), 1 (3x bf16) or 3 (1x bf16)");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_x3: drop_p=%f", drop_p);
     QT_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "qt_gemm_x3: leading dimension too small");
     // K-contiguous operands are staged with 16-byte loads
@@ -551,8 +578,16 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     // big tile: persistent, one resident round of workgroups walks all work items; small tile: one item each
     dim3 grid((unsigned)tiles, (unsigned)split_k, (unsigned)batch);
     if (big) grid = dim3((unsigned)(total_work > slots ? slots : total_work));
-    if (big) { if (half_type == 0) launch_x3<4, 2, 2, 4, 1, 0>(a, transA, transB, grid, st); else launch_x3<4, 2, 2, 4, 1, 1>(a, transA, transB, grid, st); }
-    else     { if (half_type == 0) launch_x3<2, 2, 2, 2, 2, 0>(a, transA, transB, grid, st); else launch_x3<2, 2, 2, 2, 2, 1>(a, transA, transB, grid, st); }
+    if (big) {
+        if (half_type == 0) qt_x3_big_0(a, transA, transB, grid, st);
+        else if (half_type == 1) qt_x3_big_1(a, transA, transB, grid, st);
+        else qt_x3_big_3(a, transA, transB, grid, st);
+    } else {
+        if (half_type == 0) qt_x3_small_0(a, transA, transB, grid, st);
+        else if (half_type == 1) qt_x3_small_1(a, transA, transB, grid, st);
+        else qt_x3_small_3(a, transA, transB, grid, st);
+    }
     QT_CHECK_LAUNCH("qt_gemm_x3");
     return QT_OK;
 }
+#endif  // QT_X3_PART == 0

@@ -283,3 +283,41 @@ def test_cpu_tensors_fail_loudly(qt, synth):
     model = qt.QA_TIGER(**cfg.model_kwargs())
     with pytest.raises(qt.QTError, match='no CPU fallback'):
         model(synth.make_inputs(cfg))
+
+
+def test_reduced_precision_mode_argmax_agreement(qt, synth):
+    """BASELINE config 5 direction: GEMMs on ONE bf16 MFMA per product (ops.precision 'bf16x1').  It is outside
+    the 1e-3 gate by construction; the check is the one config 5 names — arg-max agreement with the fp32 path —
+    plus a bound on the logit drift so that a broken kernel cannot hide behind 'reduced precision'."""
+    name = 'config2_b8'
+    g = load_golden(name)
+    cfg, seed = golden_cfg(synth, name)
+    model = build(qt, synth, cfg, seed)
+    inp = {k: v.to(DEV) for k, v in synth.make_inputs(cfg, seed).items()}
+    keep = dict(qt.ops.precision)
+    qt.ops.precision.update(fwd='bf16x1', bwd='bf16x1')
+    try:
+        with torch.no_grad():
+            out = model(inp)['out'].cpu().numpy()
+    finally:
+        qt.ops.precision.update(keep)
+    err = rel_err(out, g['logits'])
+    agree = float((out.argmax(-1) == g['logits'].argmax(-1)).mean())
+    print(f'bf16x1: rel logit err {err:.2e}, arg-max agreement {agree:.3f}')
+    assert 1e-5 < err < 5e-2          # really reduced precision, and not garbage
+    assert agree >= 0.75
+
+
+@pytest.mark.parametrize('shape', [(300, 512, 256, False, True), (512, 300, 1000, True, False), (256, 256, 4096, False, False)])
+def test_bf16x1_gemm(qt, shape):
+    M, N, K, ta, tb = shape
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    out = qt.ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, mode='bf16x1').cpu()
+    # exact reference of the mode's definition: operands rounded to bf16, products and sums in high precision
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = (ar.t() if ta else ar) @ (br.t() if tb else br)
+    assert rel_err(out.numpy(), ref.float().numpy()) < 2e-6
+    full = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    assert 1e-4 < rel_err(out.numpy(), full.float().numpy()) < 2e-2
