@@ -50,10 +50,21 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16, help='batch of the bounded CPU-baseline sample')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
+    ap.add_argument('--skip-fwd-only', action='store_true', help='skip the forward-only passes (used by tools/pmc_step_traffic.sh so that every profiled launch belongs to a train step)')
     ap.add_argument('--reduced-precision', action='store_true', help='also time the bf16x1 GEMM mode (BASELINE config 5 direction: one bf16 MFMA per product); reported beside the metric with its arg-max agreement, never as the metric')
     ap.add_argument('--text-tower', action='store_true', help='also time the frozen CLIP text tower (ViT-L/14 text side, forward, B x 77 tokens); reported beside the metric, never in it')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra instrumented steps for the roofline (after the timed region)')
     return ap.parse_args()
+
+
+def pmc_traffic(family):
+    """Average HBM-side bytes per launch from the committed PMC summary (tools/pmc_step_traffic.sh), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_step_traffic.json')
+    try:
+        with open(path) as f:
+            return round(json.load(f)[family]['hbm_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(qt, sample_b: int):
@@ -132,19 +143,21 @@ def main():
     value = per_gpu * world * args.steps / dt
 
     # ---- forward-only (eval, no_grad): the north-star's ">= 10k QA-pairs/s forward" figure
-    model.eval()
-    with torch.no_grad():
-        for _ in range(2):
-            model(batch)
-        sync()
-        t1 = time.perf_counter()
-        n_fwd = max(3, args.steps)
-        for _ in range(n_fwd):
-            model(batch)
-        sync()
-        fwd_dt = time.perf_counter() - t1
-    model.train()
-    fwd_value = per_gpu * world * n_fwd / fwd_dt
+    n_fwd = max(3, args.steps)
+    fwd_value = 0.0
+    if not args.skip_fwd_only:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(batch)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n_fwd):
+                model(batch)
+            sync()
+            fwd_dt = time.perf_counter() - t1
+        model.train()
+        fwd_value = per_gpu * world * n_fwd / fwd_dt
 
     # ---- instrumented steps: HIP events around every kernel launch of the two dominant families
     roofline = attention = None
@@ -167,12 +180,16 @@ def main():
                         kernel=('qt_gemm_x3_kernel' if split else 'qt_gemm_f32_kernel') +
                                ' (all projection/MLP GEMM launches of one train step, fwd+bwd)',
                         achieved=round(algo_tf, 2), peak=peak, unit='TFLOP/s', frac=round(algo_tf / peak, 4),
-                        traffic=None,
+                        traffic=pmc_traffic('gemm_x3') if split else None,
                         note=('achieved = reference-executed fp32 GEMM FLOPs (34.647 GFLOP/sample) / summed GEMM kernel time; '
                               'each fp32 product is issued as 3 16-bit MFMA products, so the matrix pipes see 3x executed_tflops'
                               if split else 'fp32 MFMA'),
                         algorithmic_gflop_per_sample=GFLOP_FWD_BWD, executed_tflops=round(exec_tf, 2),
                         mfma_issue_frac=round((3.0 if split else 1.0) * exec_tf / peak, 4),
+                        algorithmic_bytes_per_launch=round(sum(4.0 * (k[0] * k[2] + k[2] * k[1] + k[0] * k[1]) * (k[6] if len(k) > 6 else 1) * v[2]
+                                                               for k, v in gm['by_detail'].items()) / gm['launches']),
+                        traffic_source='profiles/r01_pmc_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --skip-fwd-only`; '
+                                       'FETCH_SIZE x2 per the gfx950 correction; average HBM-side bytes per qt_gemm_x3 launch of a train step, not measured in this run)',
                         launches_per_step=gm['launches'] // n, avg_launch_ms=round(gemm_ms / (gm['launches'] / n), 4),
                         gemm_ms_per_step=round(gemm_ms, 3), share_of_step=round(gemm_ms / ms_step, 3),
                         top_shapes=[dict(MNK_tAtB=list(k), ms_per_step=round(v[0] / n, 3), launches=v[2] // n,

@@ -28,14 +28,18 @@ extern thread_local char qt_err_buf[512];
 enum { QT_OK = 0, QT_ERR_RUNTIME = -1, QT_ERR_ARG = -2, QT_ERR_LAUNCH = -3, QT_ERR_UNSUPPORTED = -4 };
 
 // ---- counter-based dropout RNG ---------------------------------------------
-// splitmix64 finaliser over (seed, element index): stateless, so the backward
-// kernels regenerate the forward mask from the same (seed, index).
+// Stateless counter RNG over (seed, element index): the backward kernels regenerate the forward mask from
+// the same pair, nothing is stored.  32-bit mixer (two multiply-xorshift rounds, the "lowbias32" constants)
+// keyed by both seed halves: the first version used the splitmix64 finaliser, whose 64-bit multiplies run
+// at quarter rate on the vector ALU and made the dropout-carrying LayerNorm backward VALU-bound.
 __host__ __device__ inline uint32_t qt_rand_u32(uint64_t seed, uint64_t idx) {
-    uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 32);
+    uint32_t x = (uint32_t)idx + (uint32_t)seed;
+    const uint32_t hi = (uint32_t)(idx >> 32) + (uint32_t)(seed >> 32);     // index bits 32.. (zero on this path's tensors)
+    x ^= (hi << 13) | (hi >> 19);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x + (uint32_t)(seed >> 32);
 }
 // keep-probability 1-p; returns the inverted-dropout multiplier (0 or 1/(1-p))
 __host__ __device__ inline float qt_drop_mult(uint64_t seed, uint64_t idx, float p, float inv_keep) {
