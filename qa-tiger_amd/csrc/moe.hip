@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void qt_moe_treduce_fwd_kernel(
     }
 }
 
-// grid = B blocks (both streams of a sample in one block so dc has one owner).
+// grid = (B, ceil(T / MOE_TRB_TPB)) blocks (both streams of a sample in one block so dc has one owner; a first
+// version with one block per sample put 4 waves on each CU and ran at 2 TB/s).
+#define MOE_TRB_TPB 8
 // dH[(s*B+b)*T+t, e, :] = coef[b,t,e] * dR[s*B+b, e, :] * [H>0]
 // dcoef[b,t,e] = Σ_s <dR[s*B+b,e,:], H[(s*B+b)*T+t, e, :]>
 __global__ __launch_bounds__(256) void qt_moe_treduce_bwd_kernel(
@@ -141,8 +143,9 @@ __global__ __launch_bounds__(256) void qt_moe_treduce_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dv = Dh >> 2;
     // work item = (t, e): one wave each, lanes over Dh
-    for (int item = wave; item < T * K; item += 4) {
-        const int t = item / K, e = item - t * K;
+    const int t0 = blockIdx.y * MOE_TRB_TPB, tn = min(T - t0, MOE_TRB_TPB);
+    for (int item = wave; item < tn * K; item += 4) {
+        const int t = t0 + item / K, e = item % K;
         const float w = coef[((long)b * T + t) * K + e];
         float dot = 0.f;
         for (int s = 0; s < S; ++s) {
@@ -282,7 +285,7 @@ extern "C" int qt_moe_treduce_bwd(void* stream, const float* H, const float* coe
     QT_CHECK_ARG(H && coef && dR && dH && dcoef, "qt_moe_treduce_bwd: null pointer");
     QT_CHECK_ARG(S > 0 && B > 0 && T > 0 && K > 0 && Dh > 0 && Dh % 4 == 0, "qt_moe_treduce_bwd: Dh=%d must be a multiple of 4", Dh);
     QT_CHECK_ARG(qt_aligned16(H) && qt_aligned16(dR) && qt_aligned16(dH), "qt_moe_treduce_bwd: alignment");
-    hipLaunchKernelGGL(qt_moe_treduce_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(qt_moe_treduce_bwd_kernel, dim3(B, (T + MOE_TRB_TPB - 1) / MOE_TRB_TPB), dim3(256), 0, (hipStream_t)stream,
                        H, coef, dR, S, B, T, K, Dh, dH, dcoef);
     QT_CHECK_LAUNCH("qt_moe_treduce_bwd");
     return QT_OK;

@@ -143,14 +143,23 @@ __global__ __launch_bounds__(256) void qt_add_ln_bwd_kernel(LnArgs p) {
             }
         }
     }
+    // the block's four waves meet in LDS first, so the chip sends one global atomic per column per BLOCK
+    __shared__ float red[2 * 256 * LN_MAXV];
+    for (int c = threadIdx.x; c < 2 * p.D; c += 256) red[c] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < LN_MAXV; ++t) {
         const int c4 = lane + t * 64;
         if (c4 < nv) {
-            float* dg = p.dgamma + c4 * 4; float* db = p.dbeta + c4 * 4;
+            float* dg = red + c4 * 4; float* db = red + p.D + c4 * 4;
             atomicAdd(dg + 0, ag[t].x); atomicAdd(dg + 1, ag[t].y); atomicAdd(dg + 2, ag[t].z); atomicAdd(dg + 3, ag[t].w);
             atomicAdd(db + 0, ab[t].x); atomicAdd(db + 1, ab[t].y); atomicAdd(db + 2, ab[t].z); atomicAdd(db + 3, ab[t].w);
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.D; c += 256) {
+        atomicAdd(p.dgamma + c, red[c]);
+        atomicAdd(p.dbeta + c, red[p.D + c]);
     }
 }
 
@@ -203,7 +212,7 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
     hipError_t e = hipMemsetAsync(dgamma, 0, sizeof(float) * D, st);
     if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, sizeof(float) * D, st);
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_add_ln_bwd: memset: %s", hipGetErrorString(e));
-    const int blocks = (int)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512);
+    const int blocks = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);   // 2048 x 4 waves: 32 waves per CU
     hipLaunchKernelGGL(qt_add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
     QT_CHECK_LAUNCH("qt_add_ln_bwd");
     return QT_OK;

@@ -25,6 +25,7 @@ struct XAttnArgs {
     const float* u; const float* x; float* ctx; float* lse; float* asum;
     long u_is, u_rs; int n_items, H, Lq, Lk, D;
     int bch, gq;             // backward: rows per staged chunk, (query, head) slots held in LDS
+    int swap_ug;             // backward: u and dctx rows share ONE LDS buffer (dctx first, then u) so that two workgroups fit a CU
     float scale, drop_p, inv_keep; unsigned long long seed;
     // backward
     const float* dctx; const float* dasum; const float* ctx_in;
@@ -164,8 +165,12 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
 // delta = dctx·ctx + dasum·asum; dU += ds_p x_p in registers; the scalars a_d[q,p], scale·ds[q,p] and the
 // u / dctx rows are parked in LDS.  Phase 2 (wave per key row): dX_p = Σ_q a_d[q,p] dctx_q + scale ds[q,p] u_q
 // from LDS.  (LDS float atomics for dX were tried: 8 waves adding to the same 768 addresses ran 7.6 ms.)
+// With 16 (query, head) vectors of D = 768 the parked u and dctx rows take 96 KiB: one workgroup per CU, every
+// load latency of an item exposed (1.86 ms for the PatchSelecter shape).  When Lk <= 16 (each wave owns at most
+// two key rows) phase 2 runs in two halves over ONE buffer — dctx rows first, then the u rows written from
+// registers — with the dX rows kept in registers in between: 75 KiB, two workgroups per CU.
 template <int NV>
-__global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
+__global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
     constexpr int QB = 2, GQ = 16;        // (query, head) vectors per pass
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -173,8 +178,9 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
     const int nv = p.D >> 2, NQ = p.Lq * p.H, D = p.D, Lk = p.Lk;
     const int BCH = p.bch, SL = p.gq;     // host sizes them so that everything fits in 160 KiB
     float* Xs = lds;                      // [BCH][D]
+    const bool swap = p.swap_ug != 0;
     float* Us = Xs + BCH * D;             // [SL][D]
-    float* Gs = Us + SL * D;              // [SL][D]
+    float* Gs = swap ? Us : Us + SL * D;  // [SL][D]   (swap: the same buffer, holding dctx until phase 2a is done)
     float* Ad = Gs + SL * D;              // [SL][Lk]  dropped probabilities
     float* Ds = Ad + SL * Lk;             // [SL][Lk]  scale * dS
     const float* xbase = p.x + (long)n * Lk * D;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
                     cv = *reinterpret_cast<const float4*>(p.ctx_in + urow[b] * D + c4 * 4);
                 }
                 if (c4 < nv && ql + b < SL) {                       // idle waves own no LDS slot
-                    *reinterpret_cast<float4*>(Us + (ql + b) * D + c4 * 4) = u[b][t];
+                    if (!swap) *reinterpret_cast<float4*>(Us + (ql + b) * D + c4 * 4) = u[b][t];
                     *reinterpret_cast<float4*>(Gs + (ql + b) * D + c4 * 4) = g[b][t];
                 }
                 part += dot4(g[b][t], cv);
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
             xa_stage_rows(xbase, Xs, r0, BCH, Lk, D, nv);
             __syncthreads();
             const int rn = min(BCH, Lk - r0);
+#pragma unroll 1
             for (int r = 0; r < rn; ++r) {
                 float4 xv[NV];
 #pragma unroll
@@ -263,23 +270,7 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
         }
         __syncthreads();                                            // Ad / Ds / Us / Gs of this pass complete
         const int nq = min(GQ, NQ - grp * GQ);
-        for (int r = wave; r < Lk; r += XA_NT / 64) {
-            float4 dx[NV];
-#pragma unroll
-            for (int t = 0; t < NV; ++t) dx[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int qq = 0; qq < nq; ++qq) {
-                const float a = Ad[qq * Lk + r], d = Ds[qq * Lk + r];
-#pragma unroll
-                for (int t = 0; t < NV; ++t) {
-                    const int c4 = lane + t * 64;
-                    if (c4 < nv) {
-                        const float4 gv = *reinterpret_cast<const float4*>(Gs + qq * D + c4 * 4);
-                        const float4 uv = *reinterpret_cast<const float4*>(Us + qq * D + c4 * 4);
-                        dx[t].x += a * gv.x + d * uv.x; dx[t].y += a * gv.y + d * uv.y;
-                        dx[t].z += a * gv.z + d * uv.z; dx[t].w += a * gv.w + d * uv.w;
-                    }
-                }
-            }
+        auto store_row = [&](int r, const float4 (&dx)[NV]) {
 #pragma unroll
             for (int t = 0; t < NV; ++t) {
                 const int c4 = lane + t * 64;
@@ -290,6 +281,69 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_bwd_kernel(XAttnArgs p) {
                     *dst = v;
                 }
             }
+        };
+        if (!swap) {
+            for (int r = wave; r < Lk; r += XA_NT / 64) {
+                float4 dx[NV];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) dx[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int qq = 0; qq < nq; ++qq) {
+                    const float a = Ad[qq * Lk + r], d = Ds[qq * Lk + r];
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) {
+                        const int c4 = lane + t * 64;
+                        if (c4 < nv) {
+                            const float4 gv = *reinterpret_cast<const float4*>(Gs + qq * D + c4 * 4);
+                            const float4 uv = *reinterpret_cast<const float4*>(Us + qq * D + c4 * 4);
+                            dx[t].x += a * gv.x + d * uv.x; dx[t].y += a * gv.y + d * uv.y;
+                            dx[t].z += a * gv.z + d * uv.z; dx[t].w += a * gv.w + d * uv.w;
+                        }
+                    }
+                }
+                store_row(r, dx);
+            }
+        } else {
+            // Lk <= 16: this wave owns rows `wave` and `wave + 8`.  Half a: dX += a_d[q,p] dctx_q; then the
+            // buffer is refilled with the u rows (still in registers) and half b adds scale*ds[q,p] u_q.
+            float4 dx[2][NV];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int t = 0; t < NV; ++t) dx[k][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto half = [&](const float* coef) {
+#pragma unroll 1
+                for (int qq = 0; qq < nq; ++qq) {
+                    float w[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) w[k] = coef[qq * Lk + min(wave + 8 * k, Lk - 1)];
+#pragma unroll
+                    for (int t = 0; t < NV; ++t) {
+                        const int c4 = lane + t * 64;
+                        if (c4 < nv) {
+                            const float4 v = *reinterpret_cast<const float4*>(Us + qq * D + c4 * 4);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                dx[k][t].x = fmaf(w[k], v.x, dx[k][t].x); dx[k][t].y = fmaf(w[k], v.y, dx[k][t].y);
+                                dx[k][t].z = fmaf(w[k], v.z, dx[k][t].z); dx[k][t].w = fmaf(w[k], v.w, dx[k][t].w);
+                            }
+                        }
+                    }
+                }
+            };
+            half(Ad);
+            __syncthreads();                                        // every wave is done with the dctx rows
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const int c4 = lane + t * 64;
+                    if (c4 < nv && ql + b < SL) *reinterpret_cast<float4*>(Us + (ql + b) * D + c4 * 4) = u[b][t];
+                }
+            __syncthreads();
+            half(Ds);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (wave + 8 * k < Lk) store_row(wave + 8 * k, dx[k]);
         }
     }
 }
@@ -337,8 +391,11 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     const int NQ = Lq * H;
     a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
     size_t lds = 0;
+    // u and dctx rows both parked in LDS when that leaves room for two workgroups per CU; otherwise (and if every
+    // wave owns at most two key rows) they take turns in one buffer
+    a.swap_ug = (Lk <= 16 && sizeof(float) * ((size_t)XA_BCH * D + (size_t)2 * a.gq * D + (size_t)2 * a.gq * Lk) > 80 * 1024) ? 1 : 0;
     for (a.bch = XA_BCH; a.bch >= 1; a.bch >>= 1) {
-        lds = sizeof(float) * ((size_t)a.bch * D + (size_t)2 * a.gq * D + (size_t)2 * a.gq * Lk);
+        lds = sizeof(float) * ((size_t)a.bch * D + (size_t)(a.swap_ug ? 1 : 2) * a.gq * D + (size_t)2 * a.gq * Lk);
         if (lds <= 160 * 1024) break;
     }
     if (a.bch < 1) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_xattn_bwd: D=%d, Lk=%d, Lq*H=%d needs %zu B of LDS (>160 KiB)", D, Lk, NQ, lds);
