@@ -338,20 +338,18 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             // iteration earlier), then multiply tile t, so a SIMD's matrix pipe sees one wave's MFMAs beside
             // the other wave's VALU/LDS-store work.  Same LDS buffers, same barrier count, same results.
             if (nk > 0) sstore(0, ra0, rb0);
-            if (nk > 1) gload(kbeg + SBK, ra0, rb0);
+            if (late && nk > 1) gload(kbeg + SBK, ra0, rb0);
             __syncthreads();
-            // both halves issue the loads of tile t+2 as soon as tile t+1 has left the registers: the early
-            // half before it waits at the barrier, so its loads also fly during that wait
+            // The late half's loads of tile t+2 go out right after tile t+1 has left its registers; the early
+            // half issues tile t+1 at the top of step t.  (Issuing the early half's loads one step sooner too,
+            // before its barrier wait, measured 6-18 % SLOWER on the 215040-row shapes; the 16x16x32 MFMA form with
+            // 16-byte C stores measured within +-3 % and 2x slower split-K atomics.)
+            const int ahead = late ? 2 : 1;
             for (int t = 0; t < nk; ++t) {
-                if (late) {
-                    if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
-                    if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra0, rb0);
-                }
+                if (late && t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
+                if (t + ahead < nk) gload(kbeg + (t + ahead) * SBK, ra0, rb0);
                 compute(t & 1);
-                if (!late) {
-                    if (t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
-                    if (t + 2 < nk) gload(kbeg + (t + 2) * SBK, ra0, rb0);
-                }
+                if (!late && t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
                 __syncthreads();
             }
         }
