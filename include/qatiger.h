@@ -173,6 +173,10 @@ int qt_eval_counts(void* stream, const float* logits, long ld, int B, int C, con
                    const int* qtype, int n_types, long long* predicted,
                    long long* totals, long long* correct_by_type, long long* total_by_type);
 
+/* ---- feature shards ---- */
+/* dst[i] = (float)src[i] for fp16 feature shards (the reference casts per batch in get_items, src/trainutils.py:223-250). */
+int qt_cast_f16_f32(void* stream, const void* src_f16, float* dst, long n);
+
 #ifdef __cplusplus
 }
 #endif

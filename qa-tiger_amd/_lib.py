@@ -75,6 +75,7 @@ SIGNATURES = {
     'qt_attn_causal_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _f],
     'qt_text_embed_fwd': [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     'qt_text_eot_rows': [_p, _p, _i, _i, _i, _p, _p, _p],
+    'qt_cast_f16_f32': [_p, _p, _p, _l],
     'qt_eval_counts': [_p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p],
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
                     _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],

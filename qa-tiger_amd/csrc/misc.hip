@@ -194,3 +194,30 @@ extern "C" int qt_adam_step(void* stream, float* param, const float* grad, float
     QT_CHECK_LAUNCH("qt_adam_step");
     return QT_OK;
 }
+
+// ---- feature shards stored as fp16: widen to the fp32 the path computes in -----------
+// (the reference casts on the host, src/trainutils.py:223-250: `.float()` after `.to(device)`)
+__global__ __launch_bounds__(256) void qt_cast_f16_f32_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, long n8, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n8) {                                                   // 8 halves (16 B) in, 2 x 16 B out
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 v = *reinterpret_cast<const h8*>(src + i * 8);
+        float4 a = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        float4 b = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+        *reinterpret_cast<float4*>(dst + i * 8) = a;
+        *reinterpret_cast<float4*>(dst + i * 8 + 4) = b;
+    }
+    if (i == 0) for (long j = n8 * 8; j < n; ++j) dst[j] = (float)src[j];   // tail (< 8 elements)
+}
+
+extern "C" int qt_cast_f16_f32(void* stream, const void* src_f16, float* dst, long n) {
+    QT_CHECK_ARG(src_f16 && dst && n > 0, "qt_cast_f16_f32: bad arguments");
+    QT_CHECK_ARG(qt_aligned16(src_f16) && qt_aligned16(dst), "qt_cast_f16_f32: 16-byte alignment");
+    const long n8 = n / 8;
+    const long blocks = (n8 + 255) / 256 > 0 ? (n8 + 255) / 256 : 1;
+    QT_CHECK_ARG(blocks < (1L << 31), "qt_cast_f16_f32: too large");
+    hipLaunchKernelGGL(qt_cast_f16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16*>(src_f16), dst, n8, n);
+    QT_CHECK_LAUNCH("qt_cast_f16_f32");
+    return QT_OK;
+}
