@@ -224,6 +224,20 @@ def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int) -> Tenso
 # --------------------------------------------------------------------------- #
 # Linear:  y = dropout(relu(x W^T + b))        (reference nn.Linear call sites)
 # --------------------------------------------------------------------------- #
+# Parameters that own a slice of the flat gradient buffer (train.FlatParams sets `_qt_gv`) get their dW / db written
+# there by the producing GEMM instead of into a temporary that a hook then copies.  Only the FIRST producer of a
+# parameter in a step may do so (a second use of a shared weight would overwrite it); GradSync.begin() clears the set.
+grad_claims = set()
+
+
+def _claim_grad_view(param: Tensor):
+    gv = getattr(param, '_qt_gv', None)
+    if gv is None or id(param) in grad_claims or not gv.is_cuda:
+        return None
+    grad_claims.add(id(param))
+    return gv
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, drop_p: float, seed: int,
@@ -232,6 +246,7 @@ class LinearFn(torch.autograd.Function):
         x2 = as2d(x)
         y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'])
         ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.params = (weight, bias)                 # the Parameter objects themselves (saved tensors come back as new objects)
         ctx.cfg = (relu, drop_p, seed, bias is not None, residual is not None, grad_premasked, shape)
         return y.reshape(*shape[:-1], weight.shape[0])
 
@@ -246,10 +261,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
         want_db = has_bias and ctx.needs_input_grad[2]
+        w_param, b_param = ctx.params
         if ctx.needs_input_grad[1]:
             if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
-                db = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
-            dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db)   # [N_out, K_in] = g^T x
+                bgv = _claim_grad_view(b_param)
+                db = bgv[:] if bgv is not None else torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
+            wgv = _claim_grad_view(w_param)
+            dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db,
+                      out=None if wgv is None else wgv[:])                                   # [N_out, K_in] = g^T x
         elif want_db:
             db = colsum(g)
         if has_res and ctx.needs_input_grad[6]:

@@ -56,6 +56,8 @@ class FlatParams:
                 view.copy_(p.data)
                 p.data = view                     # the module now computes from the flat buffer
         self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+        for p, gv in zip(self.params, self.grad_views):
+            p._qt_gv = gv                          # ops.LinearFn writes dW / db straight into the flat gradient buffer
 
     def numel(self) -> int:
         return sum(p.numel() for p in self.params)
@@ -97,7 +99,8 @@ class GradSync:
         def hook(p: Tensor):
             gv = self.flat.grad_views[i]
             if p.grad is not gv:
-                gv.copy_(p.grad)
+                if p.grad.data_ptr() != gv.data_ptr():   # already in place when the producing GEMM wrote into gv
+                    gv.copy_(p.grad)
                 p.grad = gv                        # later accumulations (shared weights) add in place
             if not self._seen[i]:
                 self._seen[i] = True
@@ -118,6 +121,7 @@ class GradSync:
         hands over fresh tensors, no memset of the flat buffer needed)."""
         for p in self.flat.params:
             p.grad = None
+        ops.grad_claims.clear()                   # first producer of a parameter's gradient this step may write in place
         self._pending = [bk[2] for bk in self.buckets]
         self._seen = [False] * len(self.flat.params)
         self._fired = [False] * len(self.buckets)
