@@ -343,7 +343,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             // The late half's loads of tile t+2 go out right after tile t+1 has left its registers; the early
             // half issues tile t+1 at the top of step t.  (Issuing the early half's loads one step sooner too,
             // before its barrier wait, measured 6-18 % SLOWER on the 215040-row shapes; the 16x16x32 MFMA form with
-            // 16-byte C stores measured within +-3 % and 2x slower split-K atomics.)
+            // 16-byte C stores measured within +-3 % and 2x slower split-K atomics; cutting the tiles of the last,
+            // partial round along K so that idle CUs share them (360 tiles on 256 CUs) measured no gain: the memset
+            // and atomics cost what the shorter tail saves.)
             const int ahead = late ? 2 : 1;
             for (int t = 0; t < nk; ++t) {
                 if (late && t + 1 < nk) sstore((t + 1) & 1, ra0, rb0);
