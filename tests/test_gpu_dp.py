@@ -1,0 +1,95 @@
+"""Two-rank rehearsal of the data-parallel train step ON THE HIP KERNELS: both ranks share the box's one GPU and
+exchange gradients over gloo (RCCL needs one device per rank; the exchange code is backend-agnostic, bench.py
+uses "nccl" = RCCL on a multi-GPU node).  Checks, per rank: the flat gradient buffer after the bucketed all-reduce
+equals the SUM of the two shards' local gradients computed without any exchange (several small buckets, so the
+asynchronous path runs), and both ranks hold bit-identical parameters after the fused Adam step."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, REPO)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        qt = importlib.import_module('qa-tiger_amd')
+        train = importlib.import_module('qa-tiger_amd.train')
+        synth = qt.synth
+        dev = torch.device('cuda:0')
+        cfg = synth.PathConfig(**{**synth.CONFIG_TOY.asdict(), 'B': 6})
+        P = synth.make_state_dict(cfg, 5)
+        glob = synth.make_inputs(cfg, 5)
+        shards = [{k: v.to(dev) for k, v in train.shard_batch(glob, r, world).items()} for r in range(world)]
+
+        def fresh():
+            m = qt.QA_TIGER(**cfg.model_kwargs()); m.load_state_dict(P, strict=True)
+            return m.to(dev).eval()                              # eval: no dropout, so shards are reproducible
+
+        # reference: local gradients of every shard, no exchange, plain autograd accumulation
+        ref_model = fresh()
+        crit = qt.CrossEntropyLoss()
+        ref = None
+        for sh in shards:
+            for p in ref_model.parameters():
+                p.grad = None
+            crit(ref_model(sh)['out'], sh['label']).backward()
+            g = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in ref_model.parameters() if p.requires_grad]
+            ref = g if ref is None else [a + b for a, b in zip(ref, g)]
+
+        model = fresh()
+        eng = qt.DataParallelStep(model, lr=1e-3, betas=(0.95, 0.999), bucket_bytes=64 << 10)   # many buckets
+        assert eng.sync.world == world and len(eng.sync.buckets) > 3
+        eng.forward_backward(shards[rank])
+        torch.cuda.synchronize()
+        worst = 0.0
+        for gv, r in zip(eng.flat.grad_views, ref):
+            den = float(r.abs().max())
+            if den > 0:
+                worst = max(worst, float((gv - r).abs().max()) / den)
+        # full step, then compare parameters across ranks
+        before = eng.flat.flat.detach().clone()
+        eng.step(shards[rank])
+        torch.cuda.synchronize()
+        mine = eng.flat.flat.detach().cpu()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        same = bool(torch.equal(both[0], both[1]))
+        moved = not torch.equal(before.cpu(), mine)
+        q.put((rank, worst, same, moved))
+        dist.destroy_process_group()
+    except Exception as e:                                       # surface the failure in the parent
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), False, False))
+
+
+def test_two_rank_step_on_hip_kernels():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, worst, same, moved in res:
+        assert isinstance(worst, float), f'rank {rank} failed: {worst}'
+        assert worst < 1e-4, f'rank {rank}: all-reduced gradients differ from the sum of local gradients by {worst}'
+        assert same, 'ranks hold different parameters after the step'
+        assert moved
