@@ -238,10 +238,23 @@ def _claim_grad_view(param: Tensor):
     return gv
 
 
+class GradLink:
+    """Joins the two gradient contributions of a tensor `x` that feeds a residual block `x + f(x)`:
+    `linear(o, W, b, residual=x, link=L)` (the block's last layer) parks its residual gradient in L, and
+    `linear(x, W_in, b_in, link=L)` (the block's first layer, whose backward runs later) accumulates its dX GEMM into
+    that buffer and hands autograd no gradient of its own — instead of autograd adding two [rows, D] tensors
+    (0.32 ms per step on the 660 MB patch activations)."""
+    __slots__ = ('buf',)
+
+    def __init__(self):
+        self.buf = None
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, drop_p: float, seed: int,
-                residual: Optional[Tensor], grad_premasked: bool):
+                residual: Optional[Tensor], grad_premasked: bool, link: Optional[GradLink] = None):
+        ctx.link = link
         shape = x.shape
         x2 = as2d(x)
         y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'])
@@ -258,8 +271,13 @@ class LinearFn(torch.autograd.Function):
         if (relu or drop_p > 0.0) and not premasked:
             g = mask_grad(g, y if relu else None, drop_p, seed)
         dx = dw = db = dres = None
+        link = ctx.link
         if ctx.needs_input_grad[0]:
-            dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
+            if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], weight.shape[1]):
+                gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True)   # dx stays None
+                link.buf = None
+            else:
+                dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
         want_db = has_bias and ctx.needs_input_grad[2]
         w_param, b_param = ctx.params
         if ctx.needs_input_grad[1]:
@@ -275,12 +293,15 @@ class LinearFn(torch.autograd.Function):
             dres = g.reshape(*shape[:-1], weight.shape[0]) if not (relu or drop_p > 0.0) else None
             if dres is None:
                 raise _lib.QTError('residual with relu/dropout epilogue is not differentiable here')
-        return dx, dw, db, None, None, None, dres, None
+            if link is not None and g.dim() == 2 and g.stride(1) == 1:
+                link.buf = g                            # same memory as dres: the linked first layer adds its dX here
+        return dx, dw, db, None, None, None, dres, None, None
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False, drop_p: float = 0.0,
-           seed: int = 0, residual: Optional[Tensor] = None, grad_premasked: bool = False) -> Tensor:
-    return LinearFn.apply(x, weight, bias, relu, drop_p, seed, residual, grad_premasked)
+           seed: int = 0, residual: Optional[Tensor] = None, grad_premasked: bool = False,
+           link: Optional[GradLink] = None) -> Tensor:
+    return LinearFn.apply(x, weight, bias, relu, drop_p, seed, residual, grad_premasked, link)
 
 
 # --------------------------------------------------------------------------- #

@@ -265,9 +265,10 @@ class PatchSelecter(nn.Module):
         nxt = ops.seeds.next
         pp = patch.reshape(BT * P, D)
         # per-frame self-attention over the P patch tokens, residual, no norm (modules.py:688)
-        qkv = ops.linear(pp, *_mha_proj(self.slf_attn, 'qkv'))
+        link = ops.GradLink()                                              # d(pp) = residual gradient + in-projection dX, summed inside the dX GEMM
+        qkv = ops.linear(pp, *_mha_proj(self.slf_attn, 'qkv'), link=link)
         o = ops.attention(qkv, None, AttnSpec(BT, BT, 0, H, P, P, D, 0, D, 2 * D), p, nxt())
-        psa = ops.linear(o, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias, residual=pp)
+        psa = ops.linear(o, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias, residual=pp, link=link)
         # two queries per frame — row 0 video, row 1 audio (modules.py:692) — stacked as [video; audio]
         y2 = torch.cat([video.reshape(BT, D), audio.reshape(BT, D)], dim=0)
         qc = ops.linear(y2, *_mha_proj(self.crs_attn, 'q'))
