@@ -191,6 +191,11 @@ def main():
                         traffic_source='profiles/r01_pmc_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --skip-fwd-only`; '
                                        'FETCH_SIZE x2 per the gfx950 correction; average HBM-side bytes per qt_gemm_x3 launch of a train step, not measured in this run)',
                         launches_per_step=gm['launches'] // n, avg_launch_ms=round(gemm_ms / (gm['launches'] / n), 4),
+                        # the qt_gemm_x3_kernel launches alone (the family also counts the small exact-fp32 launches):
+                        # this is the figure to compare with the rocprofv3 kernel_stats average of qt_gemm_x3_kernel
+                        x3_launches_per_step=sum(v[2] for k, v in gm['by_detail'].items() if k[5] != 'fp32') // n,
+                        x3_avg_launch_ms=round(sum(v[0] for k, v in gm['by_detail'].items() if k[5] != 'fp32') /
+                                               max(1, sum(v[2] for k, v in gm['by_detail'].items() if k[5] != 'fp32')), 4),
                         gemm_ms_per_step=round(gemm_ms, 3), share_of_step=round(gemm_ms / ms_step, 3),
                         top_shapes=[dict(MNK_tAtB=list(k), ms_per_step=round(v[0] / n, 3), launches=v[2] // n,
                                          tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 1)) for k, v in top])
