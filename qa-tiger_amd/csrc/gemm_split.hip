@@ -33,6 +33,9 @@
 #include <utility>
 
 #define SBK 32
+#ifndef QT_MIN_SPLIT_STEPS
+#define QT_MIN_SPLIT_STEPS 4   // fewest BK steps a K split may get (tools/bench_small_gemm.py: 256x768x768 30 -> 22 us against 8; 2 is mixed)
+#endif
 #define SLD 40            // 16-bit elements per LDS row (32 + 8 pad = 80 B)
 
 struct GemmArgs {          // identical to gemm.hip
@@ -548,7 +551,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         split_k = 1;
         if (plain_epilogue && tiles * batch < 2 * slots && K >= 16 * SBK) {
             const long ovh = big ? 16 : 8;
-            long maxs = K / (8 * SBK);
+            long maxs = K / (QT_MIN_SPLIT_STEPS * SBK);
             if (maxs > 64) maxs = 64;
             long best = -1;
             for (long s = 1; s <= maxs; ++s) {
