@@ -276,3 +276,90 @@ def make_text_tokens(cfg: TextConfig, B: int, seed: int = 713) -> torch.Tensor:
         out[b, 1:1 + n] = rng.integers(1, cfg.vocab_size - 2, size=n)
         out[b, 1 + n] = eot
     return torch.from_numpy(out)
+
+
+# --------------------------------------------------------------------------- #
+# TSPM baseline model: shapes, recipe weights, inputs — oracle and goldens exist, HIP side next
+# --------------------------------------------------------------------------- #
+@dataclass(frozen=True)
+class TspmConfig:
+    """Workload of the reference's second model, `TSPM(**cfg.hyper_params.model)` (src/models/tspm.py:309-345,
+    configs/tspm/vitl14.py:37-45).  The hidden width is 512 in every sub-module (hard-coded there)."""
+    B: int = 32
+    T: int = 60
+    P: int = 14
+    Da: int = 128
+    Dv: int = 768
+    Dp: int = 1024
+    Dq: int = 768
+    topK: int = 10
+    C: int = 512
+    A: int = 42
+
+    def asdict(self):
+        return dict(B=self.B, T=self.T, P=self.P, Da=self.Da, Dv=self.Dv, Dp=self.Dp, Dq=self.Dq, topK=self.topK, C=self.C, A=self.A)
+
+    def model_kwargs(self):
+        return dict(topK=self.topK, avq_cross_attn=False, audio_dim=self.Da, vis_dim=self.Dv, patch_dim=self.Dp,
+                    qst_dim=self.Dq, hidden_size=self.C)
+
+
+TSPM_REF = TspmConfig()
+TSPM_TOY = TspmConfig(B=3, T=12, P=3, Da=32, Dv=48, Dp=40, Dq=56, topK=4)
+
+
+def tspm_param_shapes(cfg: TspmConfig) -> Dict[str, tuple]:
+    C = cfg.C
+    s: Dict[str, tuple] = {}
+
+    def lin(name, o, i):
+        s[name + '.weight'] = (o, i); s[name + '.bias'] = (o,)
+
+    def mha(name):
+        s[name + '.in_proj_weight'] = (3 * C, C); s[name + '.in_proj_bias'] = (3 * C,)
+        lin(name + '.out_proj', C, C)
+
+    def ln(name):
+        s[name + '.weight'] = (C,); s[name + '.bias'] = (C,)
+
+    lin('input_a', C, cfg.Da); lin('input_v', C, cfg.Dv); lin('input_v_patch', C, cfg.Dp)
+    lin('input_qst', C, cfg.Dq); lin('input_qst_prompt', C, cfg.Dq)
+    p = 'AV_Attn.layers.0'
+    mha(p + '.self_attn'); mha(p + '.cm_attn'); lin(p + '.linear1', C, C); lin(p + '.linear2', C, C); ln(p + '.norm1'); ln(p + '.norm2')
+    ln('AV_Attn.norm1'); ln('AV_Attn.norm2')                       # defined, never applied (norm=None, tspm.py:71-73)
+    for m in ('TemporalPerception', 'SpatioPerception'):
+        mha(m + '.attn_qst_query'); lin(m + '.qst_query_linear1', C, C); lin(m + '.qst_query_linear2', C, C); ln(m + '.qst_query_visual_norm')
+        if m == 'SpatioPerception':
+            t = m + '.TokensAttn'
+            mha(t + '.self_attn'); lin(t + '.linear1', C, C); lin(t + '.linear2', C, C); ln(t + '.norm1'); ln(t + '.norm2')
+    m = 'QstTempGrd_Module'
+    mha(m + '.attn_qst_query'); lin(m + '.qst_query_linear1', C, C); lin(m + '.qst_query_linear2', C, C); ln(m + '.qst_query_visual_norm')
+    lin('av_fusion_fc', C, 6 * C); lin('answer_pred_fc', cfg.A, C)
+    return s
+
+
+def make_tspm_state_dict(cfg: TspmConfig, seed: int = 713) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in tspm_param_shapes(cfg).items():
+        z = _normal('tspm.' + name, shape, seed)
+        is_norm = 'norm' in name.split('.')[-2]
+        if len(shape) == 2:
+            w = z * np.float32(np.sqrt((1.0 if 'in_proj' in name else 2.0) / shape[1]))
+        elif is_norm and name.endswith('.weight'):
+            w = np.float32(1.0) + np.float32(0.1) * z
+        elif is_norm:
+            w = np.float32(0.05) * z
+        else:
+            w = np.float32(0.02) * z
+        out[name] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+    return out
+
+
+def make_tspm_inputs(cfg: TspmConfig, seed: int = 713) -> Dict[str, torch.Tensor]:
+    """`reshaped_data` as TSPM.forward reads it (tspm.py:355-357): float question / prompt features [B,1,Dq]."""
+    def per_sample(name, shape):
+        return torch.from_numpy(np.stack([_normal(f'tspm.{name}[{b}]', shape, seed) for b in range(cfg.B)], 0))
+    rng = np.random.Generator(np.random.PCG64(_seed('tspm.label', seed)))
+    return dict(audio=per_sample('audio', (cfg.T, cfg.Da)), video=per_sample('video', (cfg.T, cfg.Dv)),
+                patch=per_sample('patch', (cfg.T, cfg.P, cfg.Dp)), quest=per_sample('quest', (1, cfg.Dq)),
+                prompt=per_sample('prompt', (1, cfg.Dq)), label=torch.from_numpy(rng.integers(0, cfg.A, size=(cfg.B,), dtype=np.int64)))

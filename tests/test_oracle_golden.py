@@ -192,3 +192,43 @@ def test_text_tower_is_causal(synth):
         _, w1 = text_oracle.clip_text_forward(P, text, cfg.heads)
         _, w2 = text_oracle.clip_text_forward(P, t2, cfg.heads)
     assert torch.equal(w1[:, :4], w2[:, :4]) and not torch.allclose(w1[:, 4:], w2[:, 4:])
+
+
+# ---- TSPM baseline model: oracle/tspm_oracle.py vs the reference's own TSPM class ----
+@pytest.mark.parametrize('name,cfg_kw', [('tspm_toy', None), ('tspm_ref_b2', {'B': 2})])
+def test_tspm_oracle_matches_reference(synth, name, cfg_kw):
+    import importlib
+    tspm = importlib.import_module('oracle.tspm_oracle')
+    g = load_golden(name)
+    cfg = synth.TSPM_TOY if cfg_kw is None else synth.TspmConfig(**{**synth.TSPM_REF.asdict(), **cfg_kw})
+    assert list(cfg.asdict().values()) == g['cfg'].tolist()
+    P = synth.make_tspm_state_dict(cfg, int(g['seed']))
+    assert sum(float(v.double().abs().sum()) for v in P.values()) == pytest.approx(float(g['weights_checksum']), rel=1e-12)
+    inp = synth.make_tspm_inputs(cfg, int(g['seed']))
+    taps = {}
+    loss, logits, grads = tspm.forward_backward(P, inp, cfg.topK, taps)
+    assert rel_err(logits.numpy(), g['logits']) < TOL
+    assert abs(float(loss) - float(g['loss'])) < 1e-5
+    assert np.array_equal(logits.numpy().argmax(-1), g['logits'].argmax(-1))
+    assert np.array_equal(taps['top_k_index_sort'].numpy(), g['top_k_index_sort'])          # same K time steps, temporal order
+    assert rel_err(taps['temp_weights'].detach().numpy(), g['temp_weights']) < TOL
+    for k in ('audio_tssm', 'visual_sp', 'av_feat'):
+        t = taps[k].detach().numpy()
+        want = g['tap/' + k]
+        got = t if want.shape == t.shape else t.reshape(-1)[:: t.size // 4096][:4096]
+        assert rel_err(got, want) < 5 * TOL, k
+    worst = 0.0
+    for n, gr in grads.items():
+        gn = gr.numpy()
+        if f'grad/{n}' in g:
+            ref = g[f'grad/{n}']
+            den = np.abs(ref).max()
+            if den > 0:
+                worst = max(worst, np.abs(gn - ref).max() / den)
+        else:
+            ref = g[f'gradslice/{n}']
+            den = np.abs(ref).max()
+            if den > 0:
+                worst = max(worst, np.abs(gn.reshape(-1)[:: max(1, gn.size // 256)][:256] - ref).max() / den)
+            assert np.sqrt((gn.astype(np.float64) ** 2).sum()) == pytest.approx(float(g[f'gradnorm/{n}']), rel=2e-4, abs=1e-9)
+    assert worst < 2e-4

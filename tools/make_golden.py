@@ -222,9 +222,70 @@ def text_golden(text_cfg, B, seed, full):
     return rec
 
 
+def tspm_golden(cfg, seed, full):
+    """Run the reference's own TSPM (src/models/tspm.py).  The file imports torchvision (absent here) without using it
+    on this path, so an empty module of that name is registered first; `src.models` as a package would pull in the
+    CLIP loader, so the file is loaded on its own."""
+    import importlib.util
+    for name in ('torchvision', 'torchvision.models'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    spec = importlib.util.spec_from_file_location('ref_tspm', os.path.join(REF, 'src', 'models', 'tspm.py'))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    torch.manual_seed(0)
+    model = ref.TSPM(**cfg.model_kwargs())
+    sd = synth.make_tspm_state_dict(cfg, seed)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    inp = synth.make_tspm_inputs(cfg, seed)
+    taps = {}
+    tp = model.TemporalPerception
+    orig = tp.SelectTopK
+
+    def sel(temp_weights, audio_input, visual_input, B, C, _o=orig):
+        taps['temp_weights'] = temp_weights.detach().clone()
+        oa, ov, idx = _o(temp_weights, audio_input, visual_input, B, C)
+        taps['top_k_index_sort'] = np.asarray(idx).copy()
+        taps['audio_tssm'] = oa.detach().clone()
+        return oa, ov, idx
+
+    tp.SelectTopK = sel
+    model.SpatioPerception.register_forward_hook(lambda m, a, o: taps.__setitem__('visual_sp', o.detach().clone()))
+    model.av_fusion_fc.register_forward_hook(lambda m, a, o: taps.__setitem__('av_feat', o.detach().clone()))
+    out = model({k: v for k, v in inp.items() if k != 'label'})['out']
+    loss = nn.CrossEntropyLoss()(out, inp['label'])
+    loss.backward()
+    rec = {'cfg': np.array(list(cfg.asdict().values()), dtype=np.int64), 'seed': np.int64(seed),
+           'logits': out.detach().numpy(), 'loss': np.float64(loss.item()),
+           'top_k_index_sort': taps['top_k_index_sort'], 'temp_weights': taps['temp_weights'].numpy(),
+           'weights_checksum': np.float64(sum(float(v.double().abs().sum()) for v in sd.values()))}
+    s = torch.sort(taps['temp_weights'][:, 0], dim=-1)[0]
+    rec['topk_gap'] = np.float64((s[:, -cfg.topK] - s[:, -cfg.topK - 1]).min().item())   # margin of the top-K cut
+    for k in ('audio_tssm', 'visual_sp', 'av_feat'):
+        t = taps[k].numpy()
+        rec['tap/' + k] = t if (full or t.size <= 65536) else t.reshape(-1)[:: t.size // 4096][:4096].copy()
+    for n, p in model.named_parameters():
+        g = p.grad.detach().numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        if g.size <= 4096:
+            rec[f'grad/{n}'] = g
+        else:
+            rec[f'gradnorm/{n}'] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            rec[f'gradslice/{n}'] = g.reshape(-1)[:: max(1, g.size // 256)][:256].copy()
+    return rec
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if '--tspm' in sys.argv:
+        for name, cfg, full in [('tspm_toy', synth.TSPM_TOY, True),
+                                ('tspm_ref_b2', synth.TspmConfig(**{**synth.TSPM_REF.asdict(), 'B': 2}), False)]:
+            rec = tspm_golden(cfg, 713, full)
+            path = os.path.join(OUT, f'{name}.npz')
+            np.savez_compressed(path, **rec)
+            print(f'{name}: loss={float(rec["loss"]):.6f} topk_gap={float(rec["topk_gap"]):.2e} -> {os.path.getsize(path) / 1024:.0f} KiB')
+        return
     net, modules = import_reference()
     if '--text-only' in sys.argv or '--all' in sys.argv or len(sys.argv) == 1:
         for name, tcfg, B, full in [('text_toy', synth.TEXT_TOY, 5, True), ('text_vitl14_b4', synth.TEXT_VITL14, 4, False)]:
