@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
     ap.add_argument('--skip-fwd-only', action='store_true', help='skip the forward-only passes (used by tools/pmc_step_traffic.sh so that every profiled launch belongs to a train step)')
     ap.add_argument('--reduced-precision', action='store_true', help='also time the bf16x1 GEMM mode (BASELINE config 5 direction: one bf16 MFMA per product); reported beside the metric with its arg-max agreement, never as the metric')
+    ap.add_argument('--tspm', action='store_true', help="also time the reference's second model (TSPM, SURVEY 8f row 4) train step at the same batch and feature shapes; reported beside the metric")
     ap.add_argument('--text-tower', action='store_true', help='also time the frozen CLIP text tower (ViT-L/14 text side, forward, B x 77 tokens); reported beside the metric, never in it')
     ap.add_argument('--profile-steps', type=int, default=2, help='extra instrumented steps for the roofline (after the timed region)')
     return ap.parse_args()
@@ -245,6 +246,29 @@ def main():
                        max_rel_logit_diff=round(float((ref_logits - low_logits).abs().max() / ref_logits.abs().max()), 5),
                        note='outside the 1e-3 parity gate; not the benchmarked metric')
 
+    tspm = None
+    if args.tspm and world == 1:
+        tcfg = synth.TspmConfig(**{**synth.TSPM_REF.asdict(), 'B': per_gpu})
+        torch.manual_seed(713)
+        tmodel = qt.TSPM(**tcfg.model_kwargs()).to(dev).train()
+        teng = qt.DataParallelStep(tmodel, lr=1e-4, betas=(0.95, 0.999))
+        g = torch.Generator(device=dev).manual_seed(713)
+        tb = dict(audio=torch.randn(per_gpu, tcfg.T, tcfg.Da, device=dev, generator=g), video=torch.randn(per_gpu, tcfg.T, tcfg.Dv, device=dev, generator=g),
+                  patch=torch.randn(per_gpu, tcfg.T, tcfg.P, tcfg.Dp, device=dev, generator=g), quest=torch.randn(per_gpu, 1, tcfg.Dq, device=dev, generator=g),
+                  prompt=torch.randn(per_gpu, 1, tcfg.Dq, device=dev, generator=g), label=torch.randint(0, 42, (per_gpu,), device=dev, generator=g))
+        for _ in range(args.warmup):
+            teng.step(tb)
+        sync()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            teng.step(tb)
+        sync()
+        tdt = (time.perf_counter() - t4) / args.steps
+        tspm = dict(value=round(per_gpu / tdt, 1), unit='QA-pairs/s', ms_per_step=round(tdt * 1e3, 3), batch=per_gpu,
+                    config=dict(T=tcfg.T, P=tcfg.P, hidden=tcfg.C, topK=tcfg.topK, audio_dim=tcfg.Da, vis_dim=tcfg.Dv, patch_dim=tcfg.Dp),
+                    note='train step (fwd + CE + bwd + Adam, dropout on) of src/models/tspm.py on the HIP kernels; not the benchmarked metric')
+        del teng, tmodel
+
     text_tower = None
     if args.text_tower and rank == 0:
         # on the real (non-synthetic) path this runs once per batch in front of the fusion model
@@ -290,6 +314,8 @@ def main():
             out['text_tower'] = text_tower
         if reduced is not None:
             out['reduced_precision'] = reduced
+        if tspm is not None:
+            out['tspm'] = tspm
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

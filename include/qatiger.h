@@ -177,6 +177,22 @@ int qt_eval_counts(void* stream, const float* logits, long ld, int B, int C, con
 /* dst[i] = (float)src[i] for fp16 feature shards (the reference casts per batch in get_items, src/trainutils.py:223-250). */
 int qt_cast_f16_f32(void* stream, const void* src_f16, float* dst, long n);
 
+/* ---- TSPM (src/models/tspm.py) — attention pieces its nn.MultiheadAttention(512, nhead=1) and its
+ * use of the returned attention weights need beyond qt_attn_fwd/bwd ---- */
+/* p = softmax(scale * s) per row (nullable output, saved for backward), y = dropout(p); one row = one (item, query). */
+int qt_softmax_fwd(void* stream, const float* s, long lds, long rows, int L, float scale, float drop_p,
+                   unsigned long long seed, float* p, long ldp, float* y, long ldy);
+/* ds = scale * p * (dp - sum_j dp_j p_j) with dp = dy * (dropout multiplier regenerated from seed). */
+int qt_softmax_bwd(void* stream, const float* dy, long lddy, const float* p, long ldp, long rows, int L, float scale,
+                   float drop_p, unsigned long long seed, float* ds, long ldds);
+/* out[n,i,:] = head-averaged attention weights of query row i of item n (what nn.MultiheadAttention returns with
+ * need_weights=True, average_attn_weights=True: tspm.py:99-100 -> top-K time indices at :118-125).  Addressing, kv item
+ * mapping and dropout indices as qt_attn_fwd; forward only. */
+int qt_attn_avg_weights(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                        const float* k, long ldk, long kv_is,
+                        int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                        float scale, float drop_p, unsigned long long seed, float* out);
+
 #ifdef __cplusplus
 }
 #endif

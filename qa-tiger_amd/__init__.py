@@ -18,6 +18,7 @@ from ._lib import QTError, build, load              # noqa: F401
 _sys.modules.setdefault('qa_tiger_amd', _sys.modules[__name__])
 
 from .src.models.net import QA_TIGER                # noqa: E402,F401
+from .src.models.tspm import TSPM                    # noqa: E402,F401
 from .src.models.modules import (                   # noqa: E402,F401
     Projection, AVQCrossAttn, QstGrounding, TempMoE, PatchSelecter)
 from .src.models.encoders import CLIP_TEncoder      # noqa: E402,F401

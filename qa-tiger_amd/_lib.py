@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
-SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip']
+SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
 
 
@@ -75,6 +75,9 @@ SIGNATURES = {
     'qt_attn_causal_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _f],
     'qt_text_embed_fwd': [_p, _p, _i, _i, _i, _i, _p, _p, _p],
     'qt_text_eot_rows': [_p, _p, _i, _i, _i, _p, _p, _p],
+    'qt_softmax_fwd': [_p, _p, _l, _l, _i, _f, _f, _u64, _p, _l, _p, _l],
+    'qt_softmax_bwd': [_p, _p, _l, _p, _l, _l, _i, _f, _f, _u64, _p, _l],
+    'qt_attn_avg_weights': [_p, _p, _l, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],
     'qt_cast_f16_f32': [_p, _p, _p, _l],
     'qt_eval_counts': [_p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p],
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,

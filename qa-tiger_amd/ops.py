@@ -771,3 +771,103 @@ def eval_counts(logits: Tensor, label: Tensor, qtype: Optional[Tensor] = None, n
     _lib.check(_lib.load().qt_eval_counts(_stream(), _ptr(logits), _ld(logits), B, Cn, _ptr(label), _ptr(qtype), n_types,
                                           _ptr(pred), _ptr(totals), _ptr(correct_by_type), _ptr(total_by_type)), 'qt_eval_counts')
     return pred, totals, correct_by_type, total_by_type
+
+
+# --------------------------------------------------------------------------- #
+# single-head attention with a large head dimension, built from batched GEMMs + row softmax (csrc/softmax.hip)
+# (TSPM's nn.MultiheadAttention(512, nhead=1), reference src/models/tspm.py:20-21, 194), and the head-averaged
+# attention weights nn.MultiheadAttention returns (tspm.py:99-100)
+# --------------------------------------------------------------------------- #
+def _batched(a: Tensor, b: Tensor, out: Tensor, nb: int, a_bs: int, b_bs: int, c_bs: int, trans_a=False, trans_b=True, mode='fp32'):
+    """`nb` equal problems; `a`, `b`, `out` are views of the FIRST one (unit column stride), the others follow at the
+    given element strides."""
+    return gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, mode=mode, batch=(nb, a_bs, b_bs, c_bs))
+
+
+class BmmAttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(E)) -> dropout -> v for ONE head of width E (any multiple of 4), items of Lq / Lk consecutive
+    rows; query item n reads kv item (n + kv_shift) % n_items.  q in columns [q_col, q_col+E) of `qbuf`, k / v in columns
+    [k_col, ..) / [v_col, ..) of `kvbuf` (None: packed in `qbuf`).  Scores and probabilities are materialised
+    ([n_items*Lq, Lk]); every product is a batched GEMM over the items."""
+
+    @staticmethod
+    def forward(ctx, qbuf: Tensor, kvbuf: Optional[Tensor], n_items: int, Lq: int, Lk: int, E: int, q_col: int, k_col: int,
+                v_col: int, kv_shift: int, drop_p: float, seed: int):
+        qb = as2d(qbuf)
+        kb = qb if kvbuf is None else as2d(kvbuf)
+        _dev(qb, kb)
+        scale = 1.0 / math.sqrt(E)
+        S = torch.empty((n_items * Lq, Lk), device=qb.device, dtype=torch.float32)
+        parts = [(0, n_items, kv_shift % n_items)] if kv_shift % n_items == 0 else \
+            [(0, n_items - kv_shift % n_items, kv_shift % n_items), (n_items - kv_shift % n_items, n_items, -(n_items - kv_shift % n_items))]
+        mode_f = precision['fwd']
+        for lo, hi, sh in parts:                                   # items [lo, hi) read kv items [lo+sh, hi+sh)
+            _batched(qb[lo * Lq:lo * Lq + Lq, q_col:q_col + E], kb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, k_col:k_col + E],
+                     S[lo * Lq:lo * Lq + Lq], hi - lo, Lq * _ld(qb), Lk * _ld(kb), Lq * Lk, trans_b=True, mode=mode_f)
+        P = torch.empty_like(S)
+        Y = S                                                       # dropped probabilities overwrite the scores
+        _lib.check(_lib.load().qt_softmax_fwd(_stream(), _ptr(S), Lk, n_items * Lq, Lk, scale, float(drop_p), C.c_ulonglong(seed),
+                                              _ptr(P), Lk, _ptr(Y), Lk), 'qt_softmax_fwd')
+        O = torch.empty((n_items * Lq, E), device=qb.device, dtype=torch.float32)
+        for lo, hi, sh in parts:
+            _batched(Y[lo * Lq:lo * Lq + Lq], kb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, v_col:v_col + E], O[lo * Lq:lo * Lq + Lq],
+                     hi - lo, Lq * Lk, Lk * _ld(kb), Lq * E, trans_b=False, mode=mode_f)
+        ctx.save_for_backward(qb, kb if kvbuf is not None else None, P)
+        ctx.cfg = (n_items, Lq, Lk, E, q_col, k_col, v_col, parts, drop_p, seed, scale, qbuf.shape, None if kvbuf is None else kvbuf.shape)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO: Tensor):
+        qb, kb_saved, P = ctx.saved_tensors
+        n_items, Lq, Lk, E, q_col, k_col, v_col, parts, drop_p, seed, scale, qshape, kvshape = ctx.cfg
+        packed = kb_saved is None
+        kb = qb if packed else kb_saved
+        dO = as2d(dO.contiguous())
+        mode_b = precision['bwd']
+        dqb = torch.zeros_like(qb, memory_format=torch.contiguous_format)
+        dkb = dqb if packed else torch.zeros_like(kb, memory_format=torch.contiguous_format)
+        # the dropped probabilities again (Y = P * mask, regenerated from the seed) instead of a second saved [rows, Lk] tensor
+        dY = torch.empty_like(P)
+        lib = _lib.load()
+        if drop_p > 0.0:
+            Y = torch.empty_like(P)
+            _lib.check(lib.qt_mask_grad(_stream(), _ptr(P), Lk, None, 0, float(drop_p), C.c_ulonglong(seed), _ptr(Y), Lk, n_items * Lq, Lk), 'qt_mask_grad')
+        else:
+            Y = P
+        for lo, hi, sh in parts:
+            nb = hi - lo
+            # dV[kv item] = Y^T dO ;  dY = dO V^T
+            _batched(Y[lo * Lq:lo * Lq + Lq], dO[lo * Lq:lo * Lq + Lq], dkb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, v_col:v_col + E],
+                     nb, Lq * Lk, Lq * E, Lk * _ld(dkb), trans_a=True, trans_b=False, mode=mode_b)
+            _batched(dO[lo * Lq:lo * Lq + Lq], kb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, v_col:v_col + E], dY[lo * Lq:lo * Lq + Lq],
+                     nb, Lq * E, Lk * _ld(kb), Lq * Lk, trans_b=True, mode=mode_b)
+        dS = dY
+        _lib.check(lib.qt_softmax_bwd(_stream(), _ptr(dY), Lk, _ptr(P), Lk, n_items * Lq, Lk, scale, float(drop_p), C.c_ulonglong(seed),
+                                      _ptr(dS), Lk), 'qt_softmax_bwd')
+        for lo, hi, sh in parts:
+            nb = hi - lo
+            # dQ = dS K ;  dK[kv item] = dS^T Q
+            _batched(dS[lo * Lq:lo * Lq + Lq], kb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, k_col:k_col + E], dqb[lo * Lq:lo * Lq + Lq, q_col:q_col + E],
+                     nb, Lq * Lk, Lk * _ld(kb), Lq * _ld(dqb), trans_b=False, mode=mode_b)
+            _batched(dS[lo * Lq:lo * Lq + Lq], qb[lo * Lq:lo * Lq + Lq, q_col:q_col + E], dkb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, k_col:k_col + E],
+                     nb, Lq * Lk, Lq * _ld(qb), Lk * _ld(dkb), trans_a=True, trans_b=False, mode=mode_b)
+        return (dqb.reshape(qshape), None if packed else dkb.reshape(kvshape)) + (None,) * 10
+
+
+def bmm_attention(qbuf: Tensor, kvbuf: Optional[Tensor], n_items: int, Lq: int, Lk: int, E: int, q_col: int, k_col: int, v_col: int,
+                  kv_shift: int = 0, drop_p: float = 0.0, seed: int = 0) -> Tensor:
+    return BmmAttentionFn.apply(qbuf, kvbuf, n_items, Lq, Lk, E, q_col, k_col, v_col, kv_shift, drop_p, seed)
+
+
+def attention_avg_weights(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float = 0.0, seed: int = 0) -> Tensor:
+    """Head-averaged attention weights [n_items, Lq, Lk] of the attention `attention(qbuf, kvbuf, s, drop_p, seed)` applies
+    (no gradient: the reference only takes arg-sorts of them, tspm.py:118-125)."""
+    qb, kb = as2d(qbuf.detach()), as2d(kvbuf.detach())
+    _dev(qb, kb)
+    out = torch.empty((s.n_items, s.Lq, s.Lk), device=qb.device, dtype=torch.float32)
+    f4 = 4
+    _lib.check(_lib.load().qt_attn_avg_weights(
+        _stream(), C.c_void_p(qb.data_ptr() + s.q_col * f4), _ld(qb), s.q_is, s.q_rs,
+        C.c_void_p(kb.data_ptr() + s.k_col * f4), _ld(kb), s.Lk, s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh,
+        s.scale, float(drop_p), C.c_ulonglong(seed), _ptr(out)), 'qt_attn_avg_weights')
+    return out
