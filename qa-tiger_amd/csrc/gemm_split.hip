@@ -520,7 +520,10 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         const long spanB = transB ? ((long)N * ldb + 32) : ((long)32 * ldb + N);
         if (spanA * 4 >= (1L << 32) || spanB * 4 >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: operand spans more than 4 GiB");
     }
-    if ((long)M * N < 128L * 128L || M < 64 || N < 64) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: problem too small for the 128x128 tile");
+    // one problem: small ones belong to the exact-fp32 kernel's 64x64 tiles.  Many small problems in one launch (TSPM's
+    // 60x60x512 score / gradient products, one per item) still fill the chip with one 128x128 tile each.
+    if (batch == 1 ? ((long)M * N < 128L * 128L || M < 64 || N < 64) : (M < 16 || N < 16))
+        QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: problem too small for the 128x128 tile");
     hipStream_t st = (hipStream_t)stream;
     GemmArgs a;
     a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
@@ -549,7 +552,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         // rounds of resident workgroups x (BK steps per workgroup + a fixed prologue/epilogue/atomics
         // overhead worth `ovh` steps); minimise it.
         split_k = 1;
-        if (plain_epilogue && tiles * batch < 2 * slots && K >= 16 * SBK) {
+        if (plain_epilogue && tiles * batch < 2 * slots && K >= 16 * SBK && batch <= 16) {   // (a split needs one memset per problem)
             const long ovh = big ? 16 : 8;
             long maxs = K / (QT_MIN_SPLIT_STEPS * SBK);
             if (maxs > 64) maxs = 64;

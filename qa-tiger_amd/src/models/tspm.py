@@ -37,6 +37,14 @@ def _p(mod: nn.Module) -> float:
     return 0.1 if mod.training else 0.0
 
 
+def _single_head_attention(qkv: Tensor, n: int, L: int, C: int, shift: int, p: float, seed: int) -> Tensor:
+    """Packed-QKV self/cross attention with ONE head of width C.  Short sequences (the 14 patch tokens) fit the generic
+    attention kernel's LDS tiles even at d_h = 512; longer ones (T = 60) go through batched GEMMs + row softmax."""
+    if 4 * (4 * L * (C + 1) + 2 * L * (L + 1)) <= 160 * 1024:
+        return ops.attention(qkv, None, AttnSpec(n, n, shift, 1, L, L, C, 0, C, 2 * C), p, seed)
+    return ops.bmm_attention(qkv, None, n, L, L, C, 0, C, 2 * C, kv_shift=shift, drop_p=p, seed=seed)
+
+
 class AVHanLayer(nn.Module):
     """reference tspm.py:15-47 (nhead = 1)"""
 
@@ -54,9 +62,9 @@ class AVHanLayer(nn.Module):
         """x [2B,T,C] = [audio; video]; item n cross-attends to item (n+B) mod 2B."""
         C, p, nxt = self.d_model, _p(self), ops.seeds.next
         qkv = ops.linear(x, *_mha_proj(self.cm_attn, 'qkv'))
-        o1 = ops.bmm_attention(qkv, None, 2 * B, T, T, C, 0, C, 2 * C, kv_shift=B, drop_p=p, seed=nxt())
+        o1 = _single_head_attention(qkv, 2 * B, T, C, B, p, nxt())
         qkv = ops.linear(x, *_mha_proj(self.self_attn, 'qkv'))
-        o2 = ops.bmm_attention(qkv, None, 2 * B, T, T, C, 0, C, 2 * C, kv_shift=0, drop_p=p, seed=nxt())
+        o2 = _single_head_attention(qkv, 2 * B, T, C, 0, p, nxt())
         s1 = ops.linear(o1, self.cm_attn.out_proj.weight, self.cm_attn.out_proj.bias).reshape(2 * B, T, C)
         s2 = ops.linear(o2, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias).reshape(2 * B, T, C)
         x = ops.add_layer_norm([x, s1, s2], self.norm1.weight, self.norm1.bias, drops=[False, True, True], drop_p=p)
@@ -158,7 +166,7 @@ class TokensSelfAttn(nn.Module):
         N, P, C = x.shape
         p, nxt = _p(self), ops.seeds.next
         qkv = ops.linear(x, *_mha_proj(self.self_attn, 'qkv'))
-        o = ops.bmm_attention(qkv, None, N, P, P, C, 0, C, 2 * C, drop_p=p, seed=nxt())
+        o = _single_head_attention(qkv, N, P, C, 0, p, nxt())
         s = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias).reshape(N, P, C)
         x = ops.add_layer_norm([x, s], self.norm1.weight, self.norm1.bias, drops=[False, True], drop_p=p)
         f = ops.linear(ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p, seed=nxt()),
