@@ -299,7 +299,9 @@ def main():
             'metric': 'QA-pairs/sec fwd+bwd at B=256 T=60 D=768 K=8',
             'value': round(value, 2), 'unit': 'QA-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
-            'vs_baseline': None, 'dtype': 'f32 (GEMM products as 3x fp16 MFMA fwd / 3x bf16 MFMA bwd on hi+lo-split fp32 operands, fp32 accumulate)', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32',
+            'dtype_note': 'fp32 in, fp32 out, fp32 accumulate; each GEMM product is evaluated as 3 16-bit MFMA products on hi+lo-split fp32 operands (fp16 parts forward, bf16 parts backward): logits within 1e-6 of the exact-fp32 kernels (QT_GEMM=fp32)',
+            'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: train step (fwd + CE + bwd + grad all-reduce + Adam, dropout on) on synthetic '
                                    'CLIP/VGGish/ToMe-shaped features, reference initialisers',
                        'per_gpu_batch': per_gpu, 'global_batch': per_gpu * world, 'T': cfg.T, 'D': cfg.D, 'video_dim': cfg.Dv,

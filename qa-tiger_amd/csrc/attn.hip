@@ -593,7 +593,8 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_stream_kernel(AttnArgs p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (kc0 + kt * 16 + g * 4 + j >= Lk) acc[j] = -INFINITY;
+                const int key = kc0 + kt * 16 + g * 4 + j;
+                if (key >= Lk || (p.causal && key > q)) acc[j] = -INFINITY;   // causal: the first chunk always holds key 0 <= q
                 cm = fmaxf(cm, acc[j]);
             }
             st[kt] = acc;
@@ -859,10 +860,10 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_dkv_kernel(AttnArgs p) {
     }
 }
 
-static bool attn_stream_ok(const AttnArgs& a, bool bwd) {
+static bool attn_stream_ok(const AttnArgs& a, bool bwd, bool need_lse = true) {
     if (a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 48 || a.dh == 80 || a.dh == 112) return false;
     const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
-    if (!al || !a.lse) return false;
+    if (!al || (need_lse && !a.lse)) return false;
     if (bwd && !(qt_aligned16(a.d_o) && a.lddo % 4 == 0 && a.o_fwd && qt_aligned16(a.o_fwd) && a.delta && a.n_items % a.n_kv == 0)) return false;
     return true;
 }
@@ -968,7 +969,7 @@ static int attn_fwd_impl(void* stream, const float* q, long ldq, long q_is, long
         QT_ATTN_DISPATCH(launch_fwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return QT_OK; }
     }
-    if (!causal && attn_stream_ok(a, false)) {                       // long sequences: stream K/V with an online softmax
+    if (causal ? attn_stream_ok(a, false, false) : attn_stream_ok(a, false)) {   // long sequences; causal (forward only) needs no lse: stream K/V with an online softmax
         int rc;
         QT_ATTN_STREAM_DISPATCH(launch_fwd_stream, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(stream)"); return QT_OK; }
