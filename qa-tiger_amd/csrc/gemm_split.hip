@@ -539,7 +539,14 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     // hidden behind the next tile) and its wave halves run staggered it wins on every shape of the path
     // that has 256 rows and columns, +2..30 % over the 128x128 tile.
     bool big = (M >= 256 && N >= 256);
-    if (K < 512 && (long)((M + 255) / 256) * ((N + 255) / 256) * batch < 128) big = false;   // too few 256-tiles and no K to split
+    if (big && K <= 4096) {
+        // Few 256-tiles (small batches, the M = B rows layers): a round of 512 resident 128-tiles takes ~0.68 of a round of
+        // 256 resident 256-tiles (tools/bench_mid_gemm.py: 3840x768x768 = 45 big tiles: 39 us against 62 us; 135 tiles:
+        // 102 against 68), so compare rounds.  Long-K problems (dW) keep the big tile: split-K fills the chip there.
+        const long tb = (long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+        const long rounds_small = (4 * tb + 511) / 512, rounds_big = (tb + 255) / 256;
+        if (tb <= 1024 && 0.68 * (double)rounds_small < (double)rounds_big) big = false;
+    }
     if (force == 1) big = false;
     if (force == 2) big = true;
     const int BT = big ? 256 : 128;
