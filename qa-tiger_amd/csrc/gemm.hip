@@ -299,7 +299,7 @@ extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, i
     a.split_k = split_k; a.k_per_split = kps;
     if (split_k > 1 && !accumulate) {   // partial sums are atomically added into a zeroed C
         for (int z = 0; z < batch; ++z) {
-            hipError_t e = hipMemset2DAsync(C + (long)z * c_bs, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+            hipError_t e = qt_zero_2d(C + (long)z * c_bs, ldc, M, N, st);
             if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_f32: memset: %s", hipGetErrorString(e));
         }
     }

@@ -578,7 +578,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.split_k = split_k; a.k_per_split = kps;
     if (split_k > 1 && !accumulate) {
         for (int z = 0; z < batch; ++z) {
-            hipError_t e = hipMemset2DAsync(C + (long)z * c_bs, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st);
+            hipError_t e = qt_zero_2d(C + (long)z * c_bs, ldc, M, N, st);
             if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
         }
     }

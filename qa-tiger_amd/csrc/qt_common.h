@@ -60,3 +60,17 @@ __device__ inline float qt_wave_max(float v) {
 }
 
 static inline bool qt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- zero a [M, N] region with row pitch ldc -----------------------------------
+// Contiguous regions use a 1-D memset; strided ones a small kernel.  (hipMemset2DAsync is avoided: its graph-capture
+// node faulted on replay at the primary shapes, and every entry point of this library is meant to be capturable.)
+static __global__ __launch_bounds__(256) void qt_zero2d_kernel(float* __restrict__ C, long ldc, int M, int N) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)M * N) { const long r = i / N; C[r * ldc + (i - r * N)] = 0.f; }
+}
+static inline hipError_t qt_zero_2d(float* C, long ldc, int M, int N, hipStream_t st) {
+    if (ldc == N) return hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)N, st);
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(qt_zero2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, C, ldc, M, N);
+    return hipGetLastError();
+}

@@ -198,3 +198,4 @@ def shard_batch(batch: Dict[str, Tensor], rank: int, world: int) -> Dict[str, Te
         else:
             out[k] = v
     return out
+

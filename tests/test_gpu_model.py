@@ -321,3 +321,4 @@ def test_bf16x1_gemm(qt, shape):
     assert rel_err(out.numpy(), ref.float().numpy()) < 2e-6
     full = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
     assert 1e-4 < rel_err(out.numpy(), full.float().numpy()) < 2e-2
+
