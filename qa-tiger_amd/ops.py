@@ -38,8 +38,19 @@ _HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'bf16x1': 3, 'f16x3_t128': 16, 'bf16x3_t1
 # --------------------------------------------------------------------------- #
 # plumbing
 # --------------------------------------------------------------------------- #
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_dev_index: Optional[int] = None
+
+
 def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream.  `torch.cuda.current_stream()` builds a Stream object (9 us a call, ~1 ms per
+    train step of 2000 launches — the whole step is host-bound at B = 32); the raw-handle query is ~20x cheaper."""
+    global _dev_index
+    if _raw_stream is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()       # one process drives one GPU
+    return C.c_void_p(_raw_stream(_dev_index))
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[C.c_void_p]:
