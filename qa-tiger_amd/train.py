@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional, Sequence
 
+import os as _os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -199,3 +201,46 @@ def shard_batch(batch: Dict[str, Tensor], rank: int, world: int) -> Dict[str, Te
             out[k] = v
     return out
 
+
+
+class GraphedForward:
+    """Forward pass (eval, no_grad) captured once into a HIP graph and replayed: the ~250 kernel launches of a forward
+    make small batches host-bound (B = 32: 3 ms of Python/ctypes issue time), a replay is one launch.  Shapes are frozen
+    at capture; `__call__` copies the new batch into the captured input buffers and returns the captured output dict
+    (valid until the next call).  Every kernel of the library enqueues on torch's current stream without allocating or
+    synchronising (include/qatiger.h conventions), so the capture itself needs nothing special.
+
+    ROCm 7.2 caveat, found with tools/graph_probe.py: with the runtime's graph PACKET CAPTURE on (the default), a
+    runtime blit kernel between two replays (any contiguous device-to-device `copy_` / `clone`, any `hipMemsetAsync`)
+    makes the next replay of a graph of this size end in a GPU memory-access fault; single components replay fine, an
+    ATen elementwise kernel in between is harmless, and `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0` removes the fault.  The
+    variable is read when the HIP runtime initialises, so it must be in the environment BEFORE the process first touches
+    the GPU; this class refuses to build otherwise."""
+
+    ENV = 'DEBUG_CLR_GRAPH_PACKET_CAPTURE'
+
+    def __init__(self, model: nn.Module, example: Dict[str, Tensor], warmup: int = 2):
+        if _os.environ.get(self.ENV) != '0':
+            raise ops._lib.QTError(f'GraphedForward needs {self.ENV}=0 in the environment before the process initialises the GPU '
+                                   '(ROCm 7.2: replays of packet-captured graphs fault after an intervening runtime blit)')
+        if model.training:
+            raise ValueError('GraphedForward captures the eval forward; call model.eval() first (train-mode dropout seeds '
+                             'are host-side kernel arguments and would be frozen into the graph)')
+        self.model = model
+        self.static_in = {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in example.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                     # lazy initialisation (library load, kernel attributes) outside the capture
+                model(self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = model(self.static_in)
+
+    def __call__(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        for k, v in self.static_in.items():
+            if isinstance(v, Tensor):
+                v.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        return self.static_out
