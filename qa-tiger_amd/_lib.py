@@ -27,9 +27,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP kernels for gfx950 into one in-tree shared library."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, 'qt_common.h')]
-    if not force and os.path.exists(LIB_PATH) and \
-            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+
+    if not force and fresh():
         return LIB_PATH
+    # several ranks of one node may get here together (torch.distributed.run): one builds, the others wait and re-check
+    import fcntl
+    lock = open(os.path.join(_HERE, '.build.lock'), 'w')
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and fresh():
+            return LIB_PATH
+        return _build_locked(srcs, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(srcs, verbose: bool) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     flags = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
     objdir = os.path.join(CSRC, '_obj')
