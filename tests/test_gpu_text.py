@@ -123,3 +123,18 @@ def test_eval_counts(qt):
         np.add.at(exp_t, qtype.numpy(), 1); np.add.at(exp_c, qtype.numpy(), hit.astype(np.int64))
     assert tot.cpu().tolist() == [exp_tot, exp_cor]
     assert np.array_equal(cbt.cpu().numpy(), exp_c) and np.array_equal(tbt.cpu().numpy(), exp_t)
+
+
+def test_text_tower_is_causal_on_gpu(qt, synth):
+    """The causal mask lives in the streaming MFMA attention kernel: changing token 6 must leave the features of positions
+    0..5 unchanged (up to the last bits: the small-M GEMMs combine split-K partials with atomics) and change later ones;
+    full-size tower, B = 3."""
+    cfg = synth.TEXT_VITL14
+    enc = tower(qt, synth, cfg, 5)
+    text = synth.make_text_tokens(cfg, 3, 5).to(DEV)
+    t2 = text.clone(); t2[:, 6] = (t2[:, 6] + 11) % (cfg.vocab_size - 2)
+    _, w1 = enc(text)
+    _, w2 = enc(t2)
+    scale = float(w1.abs().max())
+    assert float((w1[:, :6] - w2[:, :6]).abs().max()) < 1e-5 * scale
+    assert float((w1[:, 6:] - w2[:, 6:]).abs().max()) > 1e-2 * scale

@@ -93,3 +93,16 @@ def test_bmm_attention_matches_reference_math(qt):
         ref.backward(go)
         assert rel_err(o.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
         assert rel_err(x.grad.cpu().numpy(), qkv.grad.numpy()) < 2e-4
+
+
+def test_tspm_samples_are_independent(qt, synth):
+    """Unlike QA_TIGER (index quirk Q1), TSPM has no cross-sample coupling: a sample's logits do not depend on its batch."""
+    cfg = synth.TspmConfig(**{**synth.TSPM_TOY.asdict(), 'B': 4})
+    model = build(qt, synth, cfg, 9)
+    inp = {k: v.to(DEV) for k, v in synth.make_tspm_inputs(cfg, 9).items()}
+    with torch.no_grad():
+        full = model(inp)['out'].clone()
+        for b in (0, 3):
+            one = {k: v[b:b + 1] for k, v in inp.items()}
+            single = model(one)['out']
+            assert float((single[0] - full[b]).abs().max() / full.abs().max()) < 1e-5
