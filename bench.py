@@ -7,10 +7,17 @@
 A step = the reference's `train()` body (src/trainutils.py:273-287) on one batch
 of synthetic features: zero_grad -> QA_TIGER.forward (train mode, dropout on) ->
 CrossEntropyLoss -> backward -> [gradient all-reduce over RCCL] -> Adam.step.
-Workload = BASELINE.json configs[1]: B=256 per GPU, T=60, D=768, K=8 experts
+Workload = BASELINE.json configs[1]: global B=256, T=60, D=768, K=8 experts
 (k=8, P=14 patches, L=77 words, Da=128, Dp=1024), fp32, inputs resident in HBM.
-Weak scaling: every rank processes its own B=256 batch; the only exchange is the
-gradient all-reduce.
+--gpus N shards that GLOBAL batch over the ranks (strong scaling: 256/128/64/32
+per GPU, the table of BASELINE.md §5 and BASELINE configs[2]); the only exchange
+is the gradient all-reduce.  The same run also times the weak-scaling variant
+(B=256 per GPU) and reports it in the `weak` sub-object; --weak swaps the roles.
+
+Timing: W warm-up steps, then EXACTLY K steps between barrier+synchronize pairs
+(max over ranks) -> `value` / `ms_per_step`; every one of those K steps is also
+bracketed by HIP events on the launch stream -> `hip_event_ms` (median, min,
+max).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      dominant kernel family (projection GEMMs, MFMA-bound)
@@ -38,6 +45,10 @@ ATTN_MB_FWD = 21.6                       # attention-core algorithmic bytes per 
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_16BIT_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16/fp16 MFMA (never the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0
+DTYPE = {('f16x3', 'bf16x3'): 'f32 (3xf16 fwd / 3xbf16 bwd split)', ('f16x3', 'f16x3'): 'f32 (3xf16 split, scaled, fwd and bwd)',
+         ('fp32', 'fp32'): 'f32', ('bf16x1', 'bf16x1'): 'bf16 products, f32 accumulate'}
+ATTN_MB_FWD_BWD = 59.4                   # q,k,v,o,dO,dq,dk,dv each touched once = 21.6 * 11/4
+PMC_TRAFFIC_FILES = ['r02_pmc_step_traffic.json', 'r01_pmc_step_traffic.json']   # newest first (tools/pmc_step_traffic.sh)
 
 
 def parse():
@@ -45,10 +56,13 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (weak scaling)')
-    ap.add_argument('--strong', action='store_true', help='shard a GLOBAL batch of --batch over the ranks instead')
+    ap.add_argument('--batch', type=int, default=256, help='GLOBAL batch (strong scaling, the default) or per-GPU batch (--weak)')
+    ap.add_argument('--strong', action='store_true', help='(default) shard a GLOBAL batch of --batch over the ranks')
+    ap.add_argument('--weak', action='store_true', help='headline = weak scaling (--batch per GPU); the strong variant moves to the side object')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=16, help='batch of the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-budget', type=float, default=60.0, help='seconds of CPU work the bounded CPU-baseline sample may take (it picks the largest batch <= 256 that fits)')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='force the batch of the CPU-baseline sample (0 = pick by --cpu-budget)')
+    ap.add_argument('--no-strict-fp32', action='store_true', help='skip the exact-fp32 MFMA (QT_GEMM=fp32) comparison line')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
     ap.add_argument('--skip-fwd-only', action='store_true', help='skip the forward-only passes (used by tools/pmc_step_traffic.sh so that every profiled launch belongs to a train step)')
     ap.add_argument('--reduced-precision', action='store_true', help='also time the bf16x1 GEMM mode (BASELINE config 5 direction: one bf16 MFMA per product); reported beside the metric with its arg-max agreement, never as the metric')
@@ -60,37 +74,94 @@ def parse():
 
 def pmc_traffic(family):
     """Average HBM-side bytes per launch from the committed PMC summary (tools/pmc_step_traffic.sh), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_step_traffic.json')
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', name)
+        try:
+            with open(path) as f:
+                return round(json.load(f)[family]['hbm_bytes_per_launch']), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def cpu_model() -> str:
     try:
-        with open(path) as f:
-            return round(json.load(f)[family]['hbm_bytes_per_launch'])
-    except (OSError, KeyError, ValueError):
-        return None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
 
 
-def cpu_baseline(qt, sample_b: int):
-    """CPU oracle (port of the reference's execution plan) on this host: fwd+bwd, train mode."""
+def cpu_baseline(qt, budget_s: float, force_b: int = 0):
+    """CPU oracle (port of the reference's execution plan) on this host's cores, SURVEY.md §8(d) / BASELINE.md §4.2:
+    forward (eval, no_grad) and forward+backward+CE (train mode), >= 3 timed iterations each, median, at B = 256 or the
+    largest batch whose 3+3 iterations fit `budget_s` (calibrated on a B = 8 run)."""
     oracle = importlib.import_module('oracle.qatiger_oracle')
     synth = qt.synth
-    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': sample_b})
     cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0)))
     torch.set_num_threads(cores)
-    P = synth.make_state_dict(cfg, 713)
+    full = synth.CONFIG_2
+    P = synth.make_state_dict(full, 713)
     g = torch.Generator().manual_seed(713)
-    inp = dict(audio=torch.randn(cfg.B, cfg.T, cfg.Da, generator=g), video=torch.randn(cfg.B, cfg.T, cfg.Dv, generator=g),
-               patch=torch.randn(cfg.B, cfg.T, cfg.P, cfg.Dp, generator=g), quest_feat=torch.randn(cfg.B, cfg.Dv, generator=g),
-               words_feat=torch.randn(cfg.B, cfg.L, cfg.Dv, generator=g), label=torch.randint(0, cfg.A, (cfg.B,), generator=g))
-    small = {k: v[:2] for k, v in inp.items()}
-    oracle.forward_backward(P, small, cfg.K, cfg.k, train=True)          # thread-pool / allocator warm-up
-    times = []
-    for _ in range(2):
+
+    def inputs(B):
+        return dict(audio=torch.randn(B, full.T, full.Da, generator=g), video=torch.randn(B, full.T, full.Dv, generator=g),
+                    patch=torch.randn(B, full.T, full.P, full.Dp, generator=g), quest_feat=torch.randn(B, full.Dv, generator=g),
+                    words_feat=torch.randn(B, full.L, full.Dv, generator=g), label=torch.randint(0, full.A, (B,), generator=g))
+
+    cal = inputs(8)
+    oracle.forward_backward(P, {k: v[:2] for k, v in cal.items()}, full.K, full.k, train=True)   # thread-pool / allocator warm-up
+    t0 = time.perf_counter()
+    oracle.forward_backward(P, cal, full.K, full.k, train=True)
+    per8 = time.perf_counter() - t0
+    B = force_b
+    if not B:
+        B = 8
+        for cand in (256, 128, 64, 32, 16):
+            # 3 x (fwd+bwd) + 3 x fwd (~1/4 of it) + the first, slower touch of the larger tensors
+            if 4.5 * per8 * cand / 8.0 <= budget_s:
+                B = cand
+                break
+    inp = inputs(B)
+    f_times, fb_times = [], []
+    with torch.no_grad():
+        oracle.qa_tiger_forward(P, inp, full.K, full.k)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.qa_tiger_forward(P, inp, full.K, full.k)
+            f_times.append(time.perf_counter() - t0)
+    for _ in range(3):
         t0 = time.perf_counter()
-        oracle.forward_backward(P, inp, cfg.K, cfg.k, train=True)
-        times.append(time.perf_counter() - t0)
-    t = min(times)
-    return dict(value=round(cfg.B / t, 3), unit='QA-pairs/s', cores=cores, kind='port',
-                sample=f'oracle/qatiger_oracle.py fwd+bwd+CE, train mode, B={cfg.B} (T=60,D=768,K=8), best of 2, {t:.2f} s/iter, '
-                       f'torch {torch.__version__} CPU fp32')
+        oracle.forward_backward(P, inp, full.K, full.k, train=True)
+        fb_times.append(time.perf_counter() - t0)
+    tf, tfb = sorted(f_times)[1], sorted(fb_times)[1]
+    return dict(value=round(B / tfb, 3), unit='QA-pairs/s', cores=cores, kind='port', fwd_value=round(B / tf, 3),
+                cpu=cpu_model(), batch=B, iterations=3,
+                sample=f'oracle/qatiger_oracle.py at B={B} (T=60,D=768,K=8; the metric is quoted at B=256), median of 3: '
+                       f'fwd+bwd+CE train mode {tfb:.2f} s/iter, fwd eval/no_grad {tf:.2f} s/iter; {cores} threads on {cpu_model()}; '
+                       f'torch {torch.__version__} CPU fp32; batch picked so that the sample fits {budget_s:.0f} s of CPU work '
+                       f'(B=8 calibration: {per8:.2f} s)')
+
+
+def timed_steps(step_fn, n_steps, sync):
+    """EXACTLY n_steps between two barrier+synchronize pairs; each step also bracketed by HIP events on the launch stream
+    (torch's current stream is the stream every kernel of the library is enqueued on, ops._stream())."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+    out = None
+    sync()
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()
+        out = step_fn()
+        e1.record()
+    sync()
+    dt = time.perf_counter() - t0
+    ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    return dt, dict(median=round(med, 3), min=round(ms[0], 3), max=round(ms[-1], 3)), out
 
 
 def main():
@@ -115,7 +186,11 @@ def main():
     qt = importlib.import_module('qa-tiger_amd')
     synth, ops = qt.synth, qt.ops
 
-    per_gpu = args.batch // world if args.strong else args.batch
+    strong = not args.weak
+    if strong and args.batch % world:
+        raise SystemExit(f'global batch {args.batch} is not divisible by {world} ranks')
+    per_gpu = args.batch // world if strong else args.batch
+    alt_per_gpu = args.batch if strong else args.batch // world     # the other scaling mode, reported beside the headline
     cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': per_gpu})
     torch.manual_seed(713)                                    # reference seed (configs/qa-tiger/vitl14.py:4)
     model = qt.QA_TIGER(**cfg.model_kwargs())                 # reference initialisers, identical on every rank
@@ -128,37 +203,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax)
+        return dt
+
     for _ in range(args.warmup):
         eng.step(batch)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = eng.step(batch)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    dt, hip_ms, loss = timed_steps(lambda: eng.step(batch), args.steps, sync)
+    dt = max_over_ranks(dt)
     ms_step = dt / args.steps * 1e3
     value = per_gpu * world * args.steps / dt
 
+    # ---- the other scaling mode on the same engine (world > 1 only: at one GPU both are the same run)
+    other = None
+    if world > 1 and alt_per_gpu != per_gpu:
+        acfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': alt_per_gpu})
+        abatch = synth.fast_device_inputs(acfg, dev, seed=913 + rank)
+        for _ in range(max(1, args.warmup)):
+            eng.step(abatch)
+        adt, ahip, _ = timed_steps(lambda: eng.step(abatch), args.steps, sync)
+        adt = max_over_ranks(adt)
+        other = dict(scaling='weak' if strong else 'strong', per_gpu_batch=alt_per_gpu, global_batch=alt_per_gpu * world,
+                     value=round(alt_per_gpu * world * args.steps / adt, 2), unit='QA-pairs/s',
+                     ms_per_step=round(adt / args.steps * 1e3, 3), hip_event_ms=ahip)
+        del abatch
+
     # ---- forward-only (eval, no_grad): the north-star's ">= 10k QA-pairs/s forward" figure
     n_fwd = max(3, args.steps)
-    fwd_value = 0.0
+    fwd_value, fwd_hip = 0.0, None
     if not args.skip_fwd_only:
         model.eval()
         with torch.no_grad():
             for _ in range(2):
                 model(batch)
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(n_fwd):
-                model(batch)
-            sync()
-            fwd_dt = time.perf_counter() - t1
+            fwd_dt, fwd_hip, _ = timed_steps(lambda: model(batch), n_fwd, sync)
+            fwd_dt = max_over_ranks(fwd_dt)
         model.train()
         fwd_value = per_gpu * world * n_fwd / fwd_dt
+
+    # ---- the same step on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32 everywhere): what the split-precision
+    # GEMMs are measured against, printed beside the headline so the precision/throughput trade is in the line itself
+    strict = None
+    if world == 1 and not args.no_strict_fp32 and ops.precision['fwd'] != 'fp32':
+        keep = dict(ops.precision)
+        ops.precision.update(fwd='fp32', bwd='fp32')
+        try:
+            for _ in range(2):
+                eng.step(batch)
+            n_s = max(3, min(5, args.steps))
+            sdt, ship, _ = timed_steps(lambda: eng.step(batch), n_s, sync)
+        finally:
+            ops.precision.update(keep)
+        strict = dict(mode='QT_GEMM=fp32: every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, 157.3 TFLOP/s peak)',
+                      value=round(per_gpu * n_s / sdt, 2), unit='QA-pairs/s', ms_per_step=round(sdt / n_s * 1e3, 3),
+                      hip_event_ms=ship, steps=n_s,
+                      mfma_f32_frac=round(per_gpu * n_s / sdt * GFLOP_FWD_BWD / 1e3 / PEAK_F32_MFMA_TFLOPS, 4))
 
     # ---- instrumented steps: HIP events around every kernel launch of the two dominant families
     roofline = attention = None
@@ -181,7 +283,7 @@ def main():
                         kernel=('qt_gemm_x3_kernel' if split else 'qt_gemm_f32_kernel') +
                                ' (all projection/MLP GEMM launches of one train step, fwd+bwd)',
                         achieved=round(algo_tf, 2), peak=peak, unit='TFLOP/s', frac=round(algo_tf / peak, 4),
-                        traffic=pmc_traffic('gemm_x3') if split else None,
+                        traffic=pmc_traffic('gemm_x3')[0] if split else None,
                         note=('achieved = reference-executed fp32 GEMM FLOPs (34.647 GFLOP/sample) / summed GEMM kernel time; '
                               'each fp32 product is issued as 3 16-bit MFMA products, so the matrix pipes see 3x executed_tflops'
                               if split else 'fp32 MFMA'),
@@ -189,8 +291,9 @@ def main():
                         mfma_issue_frac=round((3.0 if split else 1.0) * exec_tf / peak, 4),
                         algorithmic_bytes_per_launch=round(sum(4.0 * (k[0] * k[2] + k[2] * k[1] + k[0] * k[1]) * (k[6] if len(k) > 6 else 1) * v[2]
                                                                for k, v in gm['by_detail'].items()) / gm['launches']),
-                        traffic_source='profiles/r01_pmc_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --skip-fwd-only`; '
-                                       'FETCH_SIZE x2 per the gfx950 correction; average HBM-side bytes per qt_gemm_x3 launch of a train step, not measured in this run)',
+                        traffic_source=f'profiles/{pmc_traffic("gemm_x3")[1]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --skip-fwd-only`, '
+                                       'tools/pmc_step_traffic.sh; FETCH_SIZE x2 per the gfx950 correction; average HBM-side bytes per split-GEMM launch of a train step; '
+                                       'PMC counters cannot be read inside an unprofiled run, so this is the committed summary, not a live value)',
                         launches_per_step=gm['launches'] // n, avg_launch_ms=round(gemm_ms / (gm['launches'] / n), 4),
                         # the qt_gemm_x3_kernel launches alone (the family also counts the small exact-fp32 launches):
                         # this is the figure to compare with the rocprofv3 kernel_stats average of qt_gemm_x3_kernel
@@ -203,11 +306,14 @@ def main():
         a_ms = (summ.get('attn_fwd', {'ms': 0})['ms'] + summ.get('attn_bwd', {'ms': 0})['ms']) / n
         a_bytes = (summ.get('attn_fwd', {'work': 0})['work'] + summ.get('attn_bwd', {'work': 0})['work']) / n
         if a_ms > 0:
-            gbs = a_bytes / (a_ms * 1e-3) / 1e9
-            attention = dict(bound='hbm', kernel='qt_attn_fwd_kernel + qt_attn_bwd_kernel (12 + 12 launches per step)',
+            gbs = ATTN_MB_FWD_BWD * 1e6 * cfg.B / (a_ms * 1e-3) / 1e9
+            attention = dict(bound='hbm', kernel='attention cores: qt_attn_{fwd,bwd}_mfma + qt_xattn_{fwd,bwd} (12 + 12 launches per step)',
                              achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
-                             algorithmic_mb_per_sample=round(a_bytes / cfg.B / 1e6, 2), ms_per_step=round(a_ms, 3),
-                             share_of_step=round(a_ms / ms_step, 3))
+                             algorithmic_mb_per_sample=ATTN_MB_FWD_BWD,
+                             note='achieved = SURVEY 8(d) algorithmic bytes (21.6 MB fwd; q,k,v,o,dO,dq,dk,dv once each = 59.4 MB fwd+bwd per sample) / summed attention kernel time; '
+                                  'kernel_mb_per_sample is what the kernels as built touch (the folded few-query attentions read raw rows and H-wide u/ctx tensors instead of projected K/V)',
+                             kernel_mb_per_sample=round(a_bytes / cfg.B / 1e6, 2), kernel_gbs=round(a_bytes / (a_ms * 1e-3) / 1e9, 1),
+                             ms_per_step=round(a_ms, 3), share_of_step=round(a_ms / ms_step, 3))
 
     reduced = None
     if args.reduced_precision and world == 1:
@@ -292,26 +398,31 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(qt, args.cpu_sample)
+        cpu = cpu_baseline(qt, args.cpu_budget, args.cpu_sample)
 
     if rank == 0:
         out = {
             'metric': 'QA-pairs/sec fwd+bwd at B=256 T=60 D=768 K=8',
             'value': round(value, 2), 'unit': 'QA-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
-            'vs_baseline': None, 'dtype': 'f32',
-            'dtype_note': 'fp32 in, fp32 out, fp32 accumulate; each GEMM product is evaluated as 3 16-bit MFMA products on hi+lo-split fp32 operands (fp16 parts forward, bf16 parts backward): logits within 1e-6 of the exact-fp32 kernels (QT_GEMM=fp32)',
+            'ms_per_step': round(ms_step, 3), 'hip_event_ms': hip_ms, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+            'vs_baseline': None, 'dtype': DTYPE.get((ops.precision['fwd'], ops.precision['bwd']), f"f32 ({ops.precision['fwd']} fwd / {ops.precision['bwd']} bwd)"),
+            'dtype_note': 'fp32 in, fp32 out, fp32 accumulate everywhere; a GEMM product a*b is evaluated as 3 16-bit MFMA products on hi+lo-split fp32 operands '
+                          '(fp16 parts, 11+11 significand bits, in the forward; bf16 parts, 8+8 bits, ~1.5e-5 relative per product, in the backward whose operands are gradients); '
+                          'logits within 1e-6 of the exact-fp32 kernels; the exact-fp32 figure is in strict_fp32',
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: train step (fwd + CE + bwd + grad all-reduce + Adam, dropout on) on synthetic '
                                    'CLIP/VGGish/ToMe-shaped features, reference initialisers',
                        'per_gpu_batch': per_gpu, 'global_batch': per_gpu * world, 'T': cfg.T, 'D': cfg.D, 'video_dim': cfg.Dv,
                        'audio_dim': cfg.Da, 'patch_dim': cfg.Dp, 'P': cfg.P, 'L': cfg.L, 'experts': cfg.K, 'topK': cfg.k,
                        'parallelism': f'dp{world}', 'backend': ('rccl' if args.backend == 'nccl' else args.backend) if world > 1 else None},
-            'fwd_only': {'value': round(fwd_value, 2), 'unit': 'QA-pairs/s', 'mode': 'eval, no_grad', 'target': 10000,
+            'fwd_only': {'value': round(fwd_value, 2), 'unit': 'QA-pairs/s', 'mode': 'eval, no_grad', 'target': 10000, 'hip_event_ms': fwd_hip,
                          'algorithmic_tflops': round(fwd_value * GFLOP_FWD * 1e9 / 1e12 / world, 1)},
+            'strict_fp32': strict,
             'loss': round(float(loss), 5),
             'roofline': roofline, 'attention': attention, 'cpu_baseline': cpu,
         }
+        if other is not None:
+            out[other['scaling']] = other
         if text_tower is not None:
             out['text_tower'] = text_tower
         if reduced is not None:

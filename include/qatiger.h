@@ -118,6 +118,7 @@ int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
  * logits [B,K], gauss_raw [B,2K] (pairs (u_e, v_e)) -> probs [B,K], topk_inds [B,k] int64
  * (sorted by descending probability), topk_probs [B,k] (renormalised), gauss [B,k,T]. */
 int qt_moe_router_fwd(void* stream, const float* logits, const float* gauss_raw, int B, int T, int K, int k,
+                      float sigma /* TempMoE(sigma=...), modules.py:361; the Gaussian width is max(sigmoid(v), 0.09) / sigma */,
                       float* probs, long long* topk_inds, float* topk_probs, float* gauss);
 /* coef[b,t,e] = sum_i [topk_inds[(b*T+t)%B, i]==e] topk_probs[b,i] gauss[b,i,t]; csum[b,e] = sum_t coef
  * (modules.py:495-533 including the repeat(T,1) index rule). */
@@ -131,7 +132,7 @@ int qt_moe_treduce_bwd(void* stream, const float* H, const float* coef, const fl
 /* dcsum (nullable) is the gradient of csum; it is folded into dcoef on the fly. */
 int qt_moe_router_bwd(void* stream, const float* dcoef, const long long* topk_inds, const float* topk_probs,
                       const float* gauss, const float* probs, const float* gauss_raw, const float* dcsum,
-                      int B, int T, int K, int k, float* dlogits, float* dgauss_raw);
+                      int B, int T, int K, int k, float sigma, float* dlogits, float* dgauss_raw);
 
 /* out[n] (+)= sum_m x[m,n]  — bias gradients of every nn.Linear. */
 int qt_colsum(void* stream, const float* x, long ldx, int M, int N, float* out, int accumulate);
@@ -145,10 +146,11 @@ int qt_mask_grad(void* stream, const float* g, long ldg, const float* y, long ld
 /* nn.CrossEntropyLoss(mean) and d loss / d logits (train.py:41, trainutils.py:278,286). */
 int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long* label, int B, int A,
                     float* loss_rows, float* loss_mean, float* dlogits, long ldd);
-/* torch.optim.Adam (weight_decay 0) on one flat buffer (trainutils.py:141-144);
- * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce). */
+/* torch.optim.Adam on one flat buffer (trainutils.py:141-144; the reference passes weight_decay from its config);
+ * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce), then weight_decay * param is added
+ * (torch's L2 form, not AdamW). */
 int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                 int step, float lr, float beta1, float beta2, float eps, float grad_scale);
+                 int step, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay);
 
 /* ---- frozen CLIP text tower (forward only) and evaluation counters ---- */
 

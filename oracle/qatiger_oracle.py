@@ -69,11 +69,13 @@ def layer_norm(P: Mapping[str, Tensor], prefix: str, x: Tensor) -> Tensor:
 
 
 def mha(P: Mapping[str, Tensor], prefix: str, xq: Tensor, xkv: Tensor, ctx: _Ctx,
-        H: int = N_HEADS) -> Tensor:
+        H: int = N_HEADS, weights_out: Optional[list] = None) -> Tensor:
     """nn.MultiheadAttention math path, batch-first restatement.
 
     xq [N,Lq,E], xkv [N,Lk,E] -> [N,Lq,E].  key == value at every call site of
     the path (reference modules.py:217-221, 338, 562, 688, 698).
+    `weights_out` (a list) receives the module's second return value: the mean over heads of the
+    (post-dropout) probabilities, [N,Lq,Lk] (need_weights=True default).
     """
     E = xq.shape[-1]
     dh = E // H
@@ -87,6 +89,8 @@ def mha(P: Mapping[str, Tensor], prefix: str, xq: Tensor, xkv: Tensor, ctx: _Ctx
     v = v.reshape(N, Lk, H, dh).transpose(1, 2)
     a = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
     a = ctx.drop(a)
+    if weights_out is not None:
+        weights_out.append(a.mean(dim=1))
     o = (a @ v).transpose(1, 2).reshape(N, Lq, E)
     return o @ P[f'{prefix}.out_proj.weight'].t() + P[f'{prefix}.out_proj.bias']
 
@@ -94,10 +98,11 @@ def mha(P: Mapping[str, Tensor], prefix: str, xq: Tensor, xkv: Tensor, ctx: _Ctx
 # --------------------------------------------------------------------------- #
 # AVQCrossAttn (reference modules.py:159-265)
 # --------------------------------------------------------------------------- #
-def avq_direction(P, src: Tensor, oth: Tensor, words: Tensor, ctx: _Ctx) -> Tensor:
-    """One direction of AVQCrossAttn.sub_forward (reference modules.py:194-235)."""
+def avq_direction(P, src: Tensor, oth: Tensor, words: Tensor, ctx: _Ctx, weights_out: Optional[list] = None) -> Tensor:
+    """One direction of AVQCrossAttn.sub_forward (reference modules.py:194-235); `weights_out` receives the
+    question-attention map the reference returns beside it (modules.py:217, 236)."""
     pre = 'crs_attn'
-    a_q = mha(P, f'{pre}.qst_attn', src, words, ctx)
+    a_q = mha(P, f'{pre}.qst_attn', src, words, ctx, weights_out=weights_out)
     a_s = mha(P, f'{pre}.slf_attn', src, src, ctx)
     a_c = mha(P, f'{pre}.crs_attn', src, oth, ctx)
     x = layer_norm(P, f'{pre}.norm1', src + ctx.drop(a_s) + ctx.drop(a_c) + ctx.drop(a_q))
@@ -105,9 +110,14 @@ def avq_direction(P, src: Tensor, oth: Tensor, words: Tensor, ctx: _Ctx) -> Tens
     return layer_norm(P, f'{pre}.norm2', x + ctx.drop(f))
 
 
-def avq_cross_attn(P, audio: Tensor, video: Tensor, words: Tensor, ctx: _Ctx):
+def avq_cross_attn(P, audio: Tensor, video: Tensor, words: Tensor, ctx: _Ctx, visualize: bool = False):
     """Both directions share weights and both read the ORIGINAL inputs
-    (reference modules.py:257-259)."""
+    (reference modules.py:257-259).  visualize=True: also [a_weight, v_weight]
+    (modules.py:261-263)."""
+    if visualize:
+        w = []
+        a, v = avq_direction(P, audio, video, words, ctx, w), avq_direction(P, video, audio, words, ctx, w)
+        return a, v, w
     return avq_direction(P, audio, video, words, ctx), avq_direction(P, video, audio, words, ctx)
 
 
@@ -139,7 +149,7 @@ def expert_centers(K: int, dtype, device) -> Tuple[Tensor, float]:
     return torch.linspace(margin, 1 - margin, K, dtype=dtype, device=device), margin
 
 
-def generate_gaussian(pred: Tensor, topk_inds: Tensor, T: int, K: int) -> Tensor:
+def generate_gaussian(pred: Tensor, topk_inds: Tensor, T: int, K: int, sigma: float = SIGMA) -> Tensor:
     """pred [B,K,2] = (tanh*margin offset, sigmoid width); topk_inds [B,k] -> [B,k,T].
 
     Restates reference modules.py:420-471: centre clamp to [0,1], width floor
@@ -148,7 +158,7 @@ def generate_gaussian(pred: Tensor, topk_inds: Tensor, T: int, K: int) -> Tensor
     centers, _ = expert_centers(K, pred.dtype, pred.device)
     c_all = centers[None, :] + pred[:, :, 0]
     c = torch.gather(c_all, 1, topk_inds).clamp(0, 1)[:, :, None]            # [B,k,1]
-    w = (torch.gather(pred[:, :, 1], 1, topk_inds).clamp(min=0.09) / SIGMA)[:, :, None]
+    w = (torch.gather(pred[:, :, 1], 1, topk_inds).clamp(min=0.09) / sigma)[:, :, None]
     tau = torch.linspace(0, 1, T, dtype=pred.dtype, device=pred.device)[None, None, :]
     g = 0.3989422804014327 / w * torch.exp(-(tau - c) ** 2 / (2 * w ** 2))
     return g / g.max(dim=-1, keepdim=True)[0]
@@ -175,7 +185,7 @@ def moe_combine(experts_out: Tensor, gauss: Tensor, topk_inds: Tensor, topk_prob
 
 
 def temp_moe(P, prefix: str, qst: Tensor, data: Tensor, sub_data: Optional[Sequence[Tensor]],
-             K: int, k: int, ctx: _Ctx):
+             K: int, k: int, ctx: _Ctx, sigma: float = SIGMA):
     """TempMoE.forward (reference modules.py:536-612).
 
     qst [B,D]; data [B,T,D]; sub_data None or [a_patch, v_patch]."""
@@ -188,7 +198,7 @@ def temp_moe(P, prefix: str, qst: Tensor, data: Tensor, sub_data: Optional[Seque
     raw = linear(P, f'{prefix}.gauss_pred.0', temp_w).view(B, K, 2)
     _, margin = expert_centers(K, raw.dtype, raw.device)
     pred = torch.stack([torch.tanh(raw[:, :, 0]) * margin, torch.sigmoid(raw[:, :, 1])], dim=-1)
-    gauss = generate_gaussian(pred, topk_inds, T, K)
+    gauss = generate_gaussian(pred, topk_inds, T, K, sigma)
     ctx.tap(f'{prefix}.temp_w', temp_w)
     ctx.tap(f'{prefix}.router_logits', router_logits)
     ctx.tap(f'{prefix}.topk_inds', topk_inds)

@@ -17,6 +17,9 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
 SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
+ABI_VERSION = 200          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
+HASH_PATH = LIB_PATH + '.srchash'
+FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
 
 class QTError(RuntimeError):
@@ -26,9 +29,15 @@ class QTError(RuntimeError):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP kernels for gfx950 into one in-tree shared library."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'qt_common.h')]
+    want = source_hash()
+
     def fresh():
-        return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)
+        # content hash, not mtimes: the tree is copied to the GPU box and file times do not survive that reliably
+        try:
+            with open(HASH_PATH) as f:
+                return os.path.exists(LIB_PATH) and f.read().strip() == want
+        except OSError:
+            return False
 
     if not force and fresh():
         return LIB_PATH
@@ -45,9 +54,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         lock.close()
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources, the shared header and the compiler flags."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for name in SOURCES + ['qt_common.h']:
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _build_locked(srcs, verbose: bool) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    flags = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
+    flags = FLAGS
     objdir = os.path.join(CSRC, '_obj')
     os.makedirs(objdir, exist_ok=True)
     # one object per translation unit, compiled in parallel; gemm_split.hip is built in parts (see its tail)
@@ -75,6 +95,8 @@ def _build_locked(srcs, verbose: bool) -> str:
     res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
         raise QTError(f'hipcc link failed:\n{res.stdout}\n{res.stderr}')
+    with open(HASH_PATH, 'w') as f:
+        f.write(source_hash() + '\n')
     return LIB_PATH
 
 
@@ -100,16 +122,16 @@ SIGNATURES = {
                     _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],
     'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
-    'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p],
+    'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p],
     'qt_moe_coef_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'qt_moe_treduce_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'qt_moe_treduce_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
-    'qt_moe_router_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    'qt_moe_router_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p],
     'qt_colsum': [_p, _p, _l, _i, _i, _p, _i],
     'qt_add_rows': [_p, _p, _l, _i, _f, _p, _l, _i, _f, _p, _l, _l, _i],
     'qt_mask_grad': [_p, _p, _l, _p, _l, _f, _u64, _p, _l, _l, _i],
     'qt_xent_fwd_bwd': [_p, _p, _l, _p, _i, _i, _p, _p, _p, _l],
-    'qt_adam_step': [_p, _p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f],
+    'qt_adam_step': [_p, _p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f],
 }
 EXPORTS = ['qt_version', 'qt_last_error'] + list(SIGNATURES)
 
@@ -117,19 +139,25 @@ _lib: Optional[C.CDLL] = None
 
 
 def load() -> C.CDLL:
-    """Load (building first if the .so is absent and hipcc is available)."""
+    """Load the library; (re)build first when it is absent or was built from other sources (content hash) and hipcc
+    is available.  A library whose ABI version differs from this binding's is refused: the ctypes signatures below
+    would otherwise turn an argument-list change into silent memory corruption."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        try:
-            build()
-        except Exception as e:  # noqa: BLE001
+    try:
+        build()                                        # hash-checked and lock-protected: a no-op for a current library
+    except Exception as e:  # noqa: BLE001
+        if not os.path.exists(LIB_PATH):
             raise QTError(f'{LIB_PATH} is missing and could not be built ({e}); '
                           'run `python -c "import __graft_entry__ as g; g.build()"`') from e
+        # no compiler here: a stale library is caught by the version check below
     lib = C.CDLL(LIB_PATH)
     lib.qt_version.restype = C.c_int
     lib.qt_last_error.restype = C.c_char_p
+    if lib.qt_version() != ABI_VERSION:
+        raise QTError(f'{LIB_PATH} reports ABI {lib.qt_version()}, this binding needs {ABI_VERSION}: rebuild it '
+                      '(`python -c "import __graft_entry__ as g; g.build()"`)')
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args

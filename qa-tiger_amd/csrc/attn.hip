@@ -860,13 +860,6 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_dkv_kernel(AttnArgs p) {
     }
 }
 
-static bool attn_stream_ok(const AttnArgs& a, bool bwd, bool need_lse = true) {
-    if (a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 48 || a.dh == 80 || a.dh == 112) return false;
-    const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
-    if (!al || (need_lse && !a.lse)) return false;
-    if (bwd && !(qt_aligned16(a.d_o) && a.lddo % 4 == 0 && a.o_fwd && qt_aligned16(a.o_fwd) && a.delta && a.n_items % a.n_kv == 0)) return false;
-    return true;
-}
 template <int DC>
 static int launch_fwd_stream(const AttnArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * 2 * SKC * (DC * 16 + 4);
@@ -896,16 +889,36 @@ static int launch_bwd_stream(const AttnArgs& a, hipStream_t st) {
         else if (dc_ == 6) rc = fn<6>(a, st); else if (dc_ == 8) rc = fn<8>(a, st); \
     } while (0)
 
-static bool attn_mfma_ok(const AttnArgs& a, bool bwd) {
-    if (a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 80 || a.dh == 48 || a.dh == 112) return false;
-    if (a.Lk > 128 || a.Lq > 64) return false;       // longer: streaming kernels (fwd too, so that lse exists for their bwd)
-    if (bwd && a.n_items % a.n_kv != 0) return false;
-    const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
-    if (!al) return false;
-    if (bwd && !(qt_aligned16(a.d_o) && a.lddo % 4 == 0)) return false;
-    return true;
-}
 static int nkt_bucket(int Lk) { const int t = (Lk + 15) / 16; return t <= 1 ? 1 : (t <= 4 ? 4 : (t <= 5 ? 5 : 8)); }
+// LDS bytes of qt_attn_bwd_mfma_kernel for this geometry (the same arithmetic as launch_bwd_mfma)
+static size_t attn_bwd_mfma_lds(int Lq, int Lk, int dh) {
+    const int DC = dh / 16, NKT = nkt_bucket(Lk);
+    const int nqt = (Lq + 15) / 16;
+    const int wpp = (nqt > 1 || NKT > 1) ? 4 : 1;
+    const int ppb = 4 / wpp;
+    const int LDK = DC * 16 + 4, KR = NKT * 16, QR = nqt * 16, LDQ = QR + 4;
+    const size_t per = (size_t)(2 * (KR > QR ? KR : QR)) * LDK + (size_t)2 * KR * LDQ;
+    return sizeof(float) * per * ppb;
+}
+// ONE predicate decides the kernel family from what forward and backward both know (geometry and the q/k/v
+// operands), so the two directions can never disagree: the MFMA forward writes no log-sum-exp, the streaming
+// backward needs one.  A geometry whose MFMA BACKWARD does not fit the 160 KiB of LDS (d_h >= 96 with
+// 81 <= Lk <= 128 and Lq > 16) therefore takes the streaming kernels in the forward too.
+enum { QT_ATTN_MFMA = 0, QT_ATTN_STREAM = 1, QT_ATTN_GENERIC = 2 };
+static int attn_path(const AttnArgs& a, bool have_lse) {
+    const bool dh_ok = !(a.dh % 16 != 0 || a.dh < 32 || a.dh > 128 || a.dh == 80 || a.dh == 48 || a.dh == 112);
+    const bool al = qt_aligned16(a.q) && qt_aligned16(a.k) && qt_aligned16(a.v) && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0;
+    if (!dh_ok || !al) return QT_ATTN_GENERIC;
+    if (a.Lk <= 128 && a.Lq <= 64 && attn_bwd_mfma_lds(a.Lq, a.Lk, a.dh) <= 160 * 1024) return QT_ATTN_MFMA;
+    return have_lse ? QT_ATTN_STREAM : QT_ATTN_GENERIC;
+}
+// what the backward kernels need beyond the forward's conditions
+static bool attn_bwd_extras_ok(const AttnArgs& a, bool stream) {
+    if (a.n_items % a.n_kv != 0) return false;
+    if (!(qt_aligned16(a.d_o) && a.lddo % 4 == 0)) return false;
+    if (stream) return a.o_fwd && qt_aligned16(a.o_fwd) && a.delta && a.lse;
+    return qt_aligned16(a.dq) && qt_aligned16(a.dk) && qt_aligned16(a.dv);
+}
 
 template <int DC, int NKT>
 static int launch_fwd_mfma(const AttnArgs& a, hipStream_t st) {
@@ -964,15 +977,20 @@ static int attn_fwd_impl(void* stream, const float* q, long ldq, long q_is, long
     a.o = o; a.ldo = ldo; a.o_is = o_is; a.o_rs = o_rs;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
     a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.lse = lse; a.causal = causal;
-    if (!causal && attn_mfma_ok(a, false)) {
+    // causal (text tower, forward only) always streams K/V with an online softmax and needs no log-sum-exp
+    int path = attn_path(a, causal || lse != nullptr);
+    if (causal && path == QT_ATTN_MFMA) path = QT_ATTN_STREAM;
+    if (path == QT_ATTN_MFMA) {
         int rc;
         QT_ATTN_DISPATCH(launch_fwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return QT_OK; }
+        QT_FAIL(QT_ERR_RUNTIME, "qt_attn_fwd: no MFMA kernel instance for d_h=%d", dh);
     }
-    if (causal ? attn_stream_ok(a, false, false) : attn_stream_ok(a, false)) {   // long sequences; causal (forward only) needs no lse: stream K/V with an online softmax
+    if (path == QT_ATTN_STREAM) {
         int rc;
         QT_ATTN_STREAM_DISPATCH(launch_fwd_stream, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(stream)"); return QT_OK; }
+        QT_FAIL(QT_ERR_RUNTIME, "qt_attn_fwd: no streaming kernel instance for d_h=%d", dh);
     }
     const int dp = dh + 1;
     const size_t lds = sizeof(float) * ((size_t)Lq * dp + (size_t)Lk * dp + (size_t)Lk * dh + (size_t)Lq * (Lk + 1));
@@ -1030,15 +1048,20 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
     a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
     a.o_fwd = o_fwd; a.lse = (float*)lse; a.delta = delta_ws;
-    if (attn_mfma_ok(a, true) && qt_aligned16(dq) && qt_aligned16(dk) && qt_aligned16(dv)) {
+    // the family the FORWARD took for this geometry (attn_path); a backward whose extra conditions fail falls to the
+    // generic kernel, which recomputes the softmax itself and needs no log-sum-exp, never to another family
+    const int path = attn_path(a, lse != nullptr);
+    if (path == QT_ATTN_MFMA && attn_bwd_extras_ok(a, false)) {
         int rc;
         QT_ATTN_DISPATCH(launch_bwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(mfma)"); return QT_OK; }
+        QT_FAIL(QT_ERR_RUNTIME, "qt_attn_bwd: MFMA kernel refused Lq=%d Lk=%d d_h=%d (rc %d)", Lq, Lk, dh, rc);
     }
-    if (attn_stream_ok(a, true)) {
+    if (path == QT_ATTN_STREAM && attn_bwd_extras_ok(a, true)) {
         int rc;
         QT_ATTN_STREAM_DISPATCH(launch_bwd_stream, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(stream)"); return QT_OK; }
+        QT_FAIL(QT_ERR_RUNTIME, "qt_attn_bwd: no streaming kernel instance for d_h=%d", dh);
     }
     const int dp = dh + 1;
     const size_t lds = sizeof(float) * (2 * (size_t)Lq * dp + 2 * (size_t)Lk * dp + 2 * (size_t)Lq * (Lk + 1));

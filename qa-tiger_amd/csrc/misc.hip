@@ -9,7 +9,7 @@
 
 thread_local char qt_err_buf[512] = "";
 
-extern "C" int qt_version(void) { return 100; }   // 0.1.0
+extern "C" int qt_version(void) { return QT_ABI_VERSION; }
 extern "C" const char* qt_last_error(void) { return qt_err_buf; }
 
 // ---- column sums ---------------------------------------------------------------
@@ -150,10 +150,10 @@ extern "C" int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const
     return QT_OK;
 }
 
-// ---- Adam on a flat buffer (weight_decay 0; bias-corrected exactly as torch.optim.Adam) --
+// ---- Adam on a flat buffer (L2 weight decay added to the gradient, bias-corrected exactly as torch.optim.Adam) --
 __global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                      float bc1, float bc2_sqrt, float grad_scale) {
+                                                      float bc1, float bc2_sqrt, float grad_scale, float wd) {
     const long nv = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, con
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
 #define QT_ADAM1(c)                                                              \
-        { const float gr = gg.c * grad_scale;                                     \
+        { const float gr = gg.c * grad_scale + wd * pp.c;                                   \
           mm.c = b1 * mm.c + (1.f - b1) * gr;                                      \
           vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                                 \
           pp.c -= (lr / bc1) * mm.c / (sqrtf(vv.c) / bc2_sqrt + eps); }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, con
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {          // tail
         const long i = (nv << 2) + threadIdx.x;
-        const float gr = g[i] * grad_scale;
+        const float gr = g[i] * grad_scale + wd * p[i];
         m[i] = b1 * m[i] + (1.f - b1) * gr;
         v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
         p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, con
 }
 
 extern "C" int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                            int step, float lr, float beta1, float beta2, float eps, float grad_scale) {
+                            int step, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay) {
     QT_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "qt_adam_step: bad arguments");
     QT_CHECK_ARG(qt_aligned16(param) && qt_aligned16(grad) && qt_aligned16(exp_avg) && qt_aligned16(exp_avg_sq),
                  "qt_adam_step: flat buffers must be 16-byte aligned");
@@ -190,7 +190,7 @@ extern "C" int qt_adam_step(void* stream, float* param, const float* grad, float
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(qt_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale);
+                       param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, weight_decay);
     QT_CHECK_LAUNCH("qt_adam_step");
     return QT_OK;
 }

@@ -25,7 +25,7 @@
 //   qt_moe_router_bwd   dc (+ dcsum) -> d router_logits, d gauss_raw
 #include "qt_common.h"
 
-#define MOE_SIGMA 9.0f      // reference modules.py:361
+// sigma (reference TempMoE.__init__ `sigma`, modules.py:361, default 9) is a kernel argument
 #define MOE_WFLOOR 0.09f    // reference modules.py:457
 #define MOE_MAXK 64
 
@@ -36,7 +36,7 @@ __device__ inline float center_of(int e, int K) {           // linspace(margin, 
 
 // grid = ceil(B/4), block = 256 (4 waves, one sample each)
 __global__ __launch_bounds__(256) void qt_moe_router_fwd_kernel(
-    const float* __restrict__ logits, const float* __restrict__ raw, int B, int T, int K, int k,
+    const float* __restrict__ logits, const float* __restrict__ raw, int B, int T, int K, int k, float sigma,
     float* __restrict__ probs, long long* __restrict__ topk_inds, float* __restrict__ topk_probs,
     float* __restrict__ gauss) {
     const int lane = threadIdx.x & 63;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void qt_moe_router_fwd_kernel(
         const float u = raw[(long)b * 2 * K + 2 * e], w_raw = raw[(long)b * 2 * K + 2 * e + 1];
         const float c = fminf(fmaxf(center_of(e, K) + tanhf(u) * margin, 0.f), 1.f);
         const float sg = 1.0f / (1.0f + expf(-w_raw));
-        const float w = fmaxf(sg, MOE_WFLOOR) / MOE_SIGMA;
+        const float w = fmaxf(sg, MOE_WFLOOR) / sigma;
         const float inv2w2 = 1.0f / (2.0f * w * w);
         float zmax = -INFINITY;
         for (int t = lane; t < T; t += 64) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void qt_moe_treduce_bwd_kernel(
 __global__ __launch_bounds__(256) void qt_moe_router_bwd_kernel(
     const float* __restrict__ dcoef, const long long* __restrict__ topk_inds, const float* __restrict__ topk_probs,
     const float* __restrict__ gauss, const float* __restrict__ probs, const float* __restrict__ raw,
-    const float* __restrict__ dcsum, int B, int T, int K, int k, float* __restrict__ dlogits, float* __restrict__ draw) {
+    const float* __restrict__ dcsum, int B, int T, int K, int k, float sigma, float* __restrict__ dlogits, float* __restrict__ draw) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void qt_moe_router_bwd_kernel(
         const float cc = center_of(e, K) + th * margin;
         const float c = fminf(fmaxf(cc, 0.f), 1.f);
         const float sg = 1.0f / (1.0f + expf(-w_raw));
-        const float w = fmaxf(sg, MOE_WFLOOR) / MOE_SIGMA;
+        const float w = fmaxf(sg, MOE_WFLOOR) / sigma;
         float dtp = 0.f, sgg = 0.f, a1 = 0.f, a2 = 0.f;
         float zbest = -INFINITY; int tbest = 0x7fffffff;
         for (int t = lane; t < T; t += 64) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void qt_moe_router_bwd_kernel(
         const float dc_center = (a1 - sgg * ds) / (w * w);
         const float dw = (a2 - sgg * ds * ds) / (w * w * w);
         const float d_off = (cc >= 0.f && cc <= 1.f) ? dc_center : 0.f;   // clamp gate (inclusive, as torch.clamp)
-        const float d_sg = (sg >= MOE_WFLOOR) ? dw / MOE_SIGMA : 0.f;
+        const float d_sg = (sg >= MOE_WFLOOR) ? dw / sigma : 0.f;
         if (lane == e) {
             du_e = d_off * margin * (1.0f - th * th);
             dv_e = d_sg * sg * (1.0f - sg);
@@ -246,12 +246,13 @@ __global__ __launch_bounds__(256) void qt_moe_router_bwd_kernel(
     }
 }
 
-extern "C" int qt_moe_router_fwd(void* stream, const float* logits, const float* gauss_raw, int B, int T, int K, int k,
+extern "C" int qt_moe_router_fwd(void* stream, const float* logits, const float* gauss_raw, int B, int T, int K, int k, float sigma,
                                  float* probs, long long* topk_inds, float* topk_probs, float* gauss) {
+    QT_CHECK_ARG(sigma > 0.f, "qt_moe_router_fwd: sigma=%f", sigma);
     QT_CHECK_ARG(logits && gauss_raw && probs && topk_inds && topk_probs && gauss, "qt_moe_router_fwd: null pointer");
     QT_CHECK_ARG(B > 0 && T > 0 && K > 0 && k > 0 && k <= K && K <= MOE_MAXK, "qt_moe_router_fwd: need 0<k<=K<=%d (K=%d k=%d)", MOE_MAXK, K, k);
     hipLaunchKernelGGL(qt_moe_router_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       logits, gauss_raw, B, T, K, k, probs, topk_inds, topk_probs, gauss);
+                       logits, gauss_raw, B, T, K, k, sigma, probs, topk_inds, topk_probs, gauss);
     QT_CHECK_LAUNCH("qt_moe_router_fwd");
     return QT_OK;
 }
@@ -293,11 +294,12 @@ extern "C" int qt_moe_treduce_bwd(void* stream, const float* H, const float* coe
 
 extern "C" int qt_moe_router_bwd(void* stream, const float* dcoef, const long long* topk_inds, const float* topk_probs,
                                  const float* gauss, const float* probs, const float* gauss_raw, const float* dcsum,
-                                 int B, int T, int K, int k, float* dlogits, float* dgauss_raw) {
+                                 int B, int T, int K, int k, float sigma, float* dlogits, float* dgauss_raw) {
+    QT_CHECK_ARG(sigma > 0.f, "qt_moe_router_bwd: sigma=%f", sigma);
     QT_CHECK_ARG(dcoef && topk_inds && topk_probs && gauss && probs && gauss_raw && dlogits && dgauss_raw, "qt_moe_router_bwd: null pointer");
     QT_CHECK_ARG(B > 0 && T > 0 && K > 0 && k > 0 && k <= K && K <= MOE_MAXK, "qt_moe_router_bwd: need 0<k<=K<=%d", MOE_MAXK);
     hipLaunchKernelGGL(qt_moe_router_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       dcoef, topk_inds, topk_probs, gauss, probs, gauss_raw, dcsum, B, T, K, k, dlogits, dgauss_raw);
+                       dcoef, topk_inds, topk_probs, gauss, probs, gauss_raw, dcsum, B, T, K, k, sigma, dlogits, dgauss_raw);
     QT_CHECK_LAUNCH("qt_moe_router_bwd");
     return QT_OK;
 }

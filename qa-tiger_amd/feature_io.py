@@ -133,7 +133,15 @@ class DeviceFeeder:
     """Double-buffered shard -> pinned host -> HBM pipeline.  `submit(names)` starts the gather + copy of a
     batch; `take()` returns the oldest submitted batch as fp32 device tensors, ordered after the copies on the
     caller's current stream; the tensors stay valid until the next `take()` (clone to keep them longer).
-    At most `depth` batches may be in flight."""
+    At most `depth` batches may be in flight.
+
+    Slot reuse is fenced on the CONSUMER's stream: a slot handed out by `take()` is released either by the next
+    `take()` or — in the submit-next-then-take loop, where `submit()` for batch i+depth comes before the `take()` that
+    would release batch i's slot — by that `submit()` itself, which records the slot's `free` event on the caller's
+    current stream before the worker starts.  The worker waits for it on the host, so the gather into pinned memory,
+    the H2D copy and the widening kernel of the new batch start only after every kernel queued so far (the train step
+    that still reads batch i, including its backward) has finished.  Work queued on batch i AFTER that `submit()`
+    is not covered: in that loop order, finish queuing the step before submitting the batch that reuses its slot."""
 
     def __init__(self, shard: FeatureShard, device, max_batch: int, depth: int = 2, workers: int = 8):
         device = torch.device(device)
@@ -149,7 +157,8 @@ class DeviceFeeder:
             out = raw if tdt == torch.float32 else {k: torch.empty((max_batch, *shape), dtype=torch.float32, device=device)
                                                      for k, shape in shard.meta['shapes'].items()}
             self.slots.append(dict(host=host, host_np={k: v.numpy() for k, v in host.items()}, raw=raw, out=out,
-                                   ready=torch.cuda.Event(), free=torch.cuda.Event(), thread=None, n=0, err=None))
+                                   ready=torch.cuda.Event(), free=torch.cuda.Event(), thread=None, n=0, err=None,
+                                   handed=False, copied=False))
         from concurrent.futures import ThreadPoolExecutor
         self.workers = max(1, workers)
         self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
@@ -165,10 +174,17 @@ class DeviceFeeder:
         slot = self.slots[self._head % self.depth]
         self._head += 1
         slot['n'], slot['err'] = len(names), None
+        if slot['handed']:                                         # still with the consumer: release it behind the work queued so far
+            slot['free'].record(torch.cuda.current_stream(self.device))
+            slot['handed'] = False
+            if self._last is slot:
+                self._last = None
 
         def work():
             try:
                 slot['free'].synchronize()                         # the consumer of this slot's previous batch is done
+                if slot['copied']:
+                    slot['ready'].synchronize()                    # ... and so is the H2D copy out of this slot's pinned staging
                 self.shard.gather(names, out=slot['host_np'], pool=self.pool, chunks=self.workers)
                 n = slot['n']
                 with torch.cuda.stream(self.stream):
@@ -179,6 +195,7 @@ class DeviceFeeder:
                             _lib.check(_lib.load().qt_cast_f16_f32(
                                 torch.cuda.current_stream().cuda_stream, src.data_ptr(), dst.data_ptr(), src.numel()), 'qt_cast_f16_f32')
                     slot['ready'].record(self.stream)
+                    slot['copied'] = True
             except Exception as e:                                  # surfaced by take()
                 slot['err'] = e
 
@@ -194,9 +211,11 @@ class DeviceFeeder:
         if slot['err'] is not None:
             raise slot['err']
         cur = torch.cuda.current_stream(self.device)
-        if self._last is not None:                                  # the previous batch is consumed by everything
+        if self._last is not None and self._last['handed']:         # the previous batch is consumed by everything
             self._last['free'].record(cur)                          # queued on this stream so far
+            self._last['handed'] = False
         cur.wait_event(slot['ready'])
         self._last = slot
+        slot['handed'] = True
         n = slot['n']
         return {k: v[:n] for k, v in slot['out'].items()}           # valid until the next take()

@@ -600,7 +600,7 @@ class MoECoefFn(torch.autograd.Function):
     plus non-differentiable diagnostics (topk_inds, topk_probs, gauss)."""
 
     @staticmethod
-    def forward(ctx, logits: Tensor, raw: Tensor, T: int, K: int, k: int):
+    def forward(ctx, logits: Tensor, raw: Tensor, T: int, K: int, k: int, sigma: float = 9.0):
         logits, raw = logits.contiguous(), raw.contiguous()
         _dev(logits, raw)
         B = logits.shape[0]
@@ -612,19 +612,19 @@ class MoECoefFn(torch.autograd.Function):
         coef = torch.empty((B, T, K), device=dev)
         csum = torch.empty((B, K), device=dev)
         lib = _lib.load()
-        _lib.check(lib.qt_moe_router_fwd(_stream(), _ptr(logits), _ptr(raw), B, T, K, k, _ptr(probs), _ptr(ti), _ptr(tp),
+        _lib.check(lib.qt_moe_router_fwd(_stream(), _ptr(logits), _ptr(raw), B, T, K, k, float(sigma), _ptr(probs), _ptr(ti), _ptr(tp),
                                          _ptr(gauss)), 'qt_moe_router_fwd')
         _lib.check(lib.qt_moe_coef_fwd(_stream(), _ptr(ti), _ptr(tp), _ptr(gauss), B, T, K, k, _ptr(coef), _ptr(csum)),
                    'qt_moe_coef_fwd')
         ctx.save_for_backward(ti, tp, gauss, probs, raw)
-        ctx.dims = (B, T, K, k)
+        ctx.dims = (B, T, K, k, float(sigma))
         ctx.mark_non_differentiable(ti, tp, gauss)
         return coef, csum, ti, tp, gauss
 
     @staticmethod
     def backward(ctx, dcoef, dcsum, _a, _b, _c):
         ti, tp, gauss, probs, raw = ctx.saved_tensors
-        B, T, K, k = ctx.dims
+        B, T, K, k, sigma = ctx.dims
         if dcoef is None:
             dcoef = torch.zeros((B, T, K), device=raw.device)
         dcoef = dcoef.contiguous()
@@ -632,9 +632,9 @@ class MoECoefFn(torch.autograd.Function):
         dlogits = torch.empty((B, K), device=raw.device)
         draw = torch.empty((B, 2 * K), device=raw.device)
         rc = _lib.load().qt_moe_router_bwd(_stream(), _ptr(dcoef), _ptr(ti), _ptr(tp), _ptr(gauss), _ptr(probs), _ptr(raw),
-                                           _ptr(dcsum), B, T, K, k, _ptr(dlogits), _ptr(draw))
+                                           _ptr(dcsum), B, T, K, k, sigma, _ptr(dlogits), _ptr(draw))
         _lib.check(rc, 'qt_moe_router_bwd')
-        return dlogits, draw, None, None, None
+        return dlogits, draw, None, None, None, None
 
 
 class MoEReduceFn(torch.autograd.Function):
@@ -698,13 +698,14 @@ def cross_entropy(logits: Tensor, label: Tensor) -> Tensor:
 
 
 def adam_step_(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
-               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0,
+               weight_decay: float = 0.0) -> None:
     """In-place torch.optim.Adam update on flat fp32 buffers."""
     _dev(param, grad, exp_avg, exp_avg_sq)
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.is_contiguous() and t.numel() == param.numel()
     rc = _lib.load().qt_adam_step(_stream(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step),
-                                  float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale))
+                                  float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale), float(weight_decay))
     _lib.check(rc, 'qt_adam_step')
 
 

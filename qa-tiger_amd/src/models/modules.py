@@ -89,9 +89,9 @@ class AVQCrossAttn(nn.Module):
         _kaiming_(self.linear2)
 
     def forward(self, src_q: Tensor, src_v: Tensor, query: Tensor, visualize: bool = False) -> List[Tensor]:
-        if visualize:
-            raise NotImplementedError('head-averaged attention maps (visualize=True, reference modules.py:261-263) '
-                                      'are not produced by the HIP attention kernel')
+        """`visualize=True` also returns `[a_weight, v_weight]`, the head-averaged question-attention maps [B,T,L] of the
+        two directions (what `nn.MultiheadAttention` returns as its second value, post-dropout in train mode; reference
+        modules.py:217, 261-263), computed by `qt_attn_avg_weights` with the forward's own dropout seed."""
         B, T, D = src_q.shape
         L = query.shape[1]
         H = self.nhead
@@ -107,7 +107,8 @@ class AVQCrossAttn(nn.Module):
         # question attention: both directions share one words K/V projection
         q = ops.linear(x, *_mha_proj(self.qst_attn, 'q'))
         kv = ops.linear(query, *_mha_proj(self.qst_attn, 'kv'))
-        o_q = ops.attention(q, kv, AttnSpec(2 * B, B, 0, H, T, L, D, 0, 0, D), p, nxt())
+        qst_spec, qst_seed = AttnSpec(2 * B, B, 0, H, T, L, D, 0, 0, D), nxt()
+        o_q = ops.attention(q, kv, qst_spec, p, qst_seed)
         a_s = ops.linear(o_s, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias).reshape(2 * B, T, D)
         a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias).reshape(2 * B, T, D)
         a_q = ops.linear(o_q, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias).reshape(2 * B, T, D)
@@ -116,6 +117,9 @@ class AVQCrossAttn(nn.Module):
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p, seed=nxt())
         f = ops.linear(h, self.linear2.weight, self.linear2.bias)
         x = ops.add_layer_norm([x, f], self.norm2.weight, self.norm2.bias, drops=[False, True], drop_p=p)
+        if visualize:
+            w = ops.attention_avg_weights(q, kv, qst_spec, p, qst_seed)       # [2B,T,L]: audio direction, then video
+            return x[:B], x[B:], [w[:B], w[B:]]
         return [x[:B], x[B:]]
 
 
@@ -137,8 +141,6 @@ class QstGrounding(nn.Module):
         (reference net.py:141) into the LayerNorm kernel."""
         d = torch.cat(list(data), dim=1) if isinstance(data, (list, tuple)) else data   # [B,S,D]
         B, S, D = d.shape
-        if S > 3:
-            raise NotImplementedError(f'QstGrounding over S={S} > 3 tokens (the path uses S=2, reference net.py:136-138)')
         p = self.dropout.p if self.training else 0.0
         q = ops.linear(qst, *_mha_proj(self.attn, 'q'))
         kv = ops.linear(d, *_mha_proj(self.attn, 'kv'))
@@ -146,10 +148,30 @@ class QstGrounding(nn.Module):
                           ops.seeds.next())
         a = ops.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
         m = ops.linear(ops.linear(a, self.mlp[0].weight, self.mlp[0].bias, relu=True), self.mlp[2].weight, self.mlp[2].bias)
-        # LayerNorm(mean_S(data) + dropout(mlp(attn)))  — the mean is S addends scaled 1/S
-        xs = [d[:, s, :] for s in range(S)] + [m]
-        return ops.add_layer_norm(xs, self.norm.weight, self.norm.bias, scales=[1.0 / S] * S + [1.0],
-                                  drops=[False] * S + [True], drop_p=p, relu_out=relu_out)
+        # LayerNorm(mean_S(data) + dropout(mlp(attn)))  — the mean is S addends scaled 1/S (the path uses S = 2, net.py:136-138);
+        # the fused kernel takes 4 addends, so a longer sequence (the reference is generic, modules.py:304-347) is summed first
+        if S <= 3:
+            xs = [d[:, s, :] for s in range(S)] + [m]
+            return ops.add_layer_norm(xs, self.norm.weight, self.norm.bias, scales=[1.0 / S] * S + [1.0],
+                                      drops=[False] * S + [True], drop_p=p, relu_out=relu_out)
+        return ops.add_layer_norm([_SumSeqFn.apply(d), m], self.norm.weight, self.norm.bias, scales=[1.0 / S, 1.0],
+                                  drops=[False, True], drop_p=p, relu_out=relu_out)
+
+
+class _SumSeqFn(torch.autograd.Function):
+    """[B,S,D] -> [B,D]: sum over the sequence axis with the row-add kernel (QstGrounding over more than 3 tokens)."""
+
+    @staticmethod
+    def forward(ctx, d: Tensor):
+        ctx.S = d.shape[1]
+        acc = ops.add_rows(d[:, 0, :], d[:, 1, :])
+        for s in range(2, d.shape[1]):
+            acc = ops.add_rows(acc, d[:, s, :])
+        return acc
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return g.unsqueeze(1).expand(g.shape[0], ctx.S, g.shape[1])
 
 
 class _AddRowsFn(torch.autograd.Function):
@@ -181,8 +203,8 @@ class TempMoE(nn.Module):
     def __init__(self, d_model: int = 512, nhead: int = 8, topK: int = 5, n_experts: int = 10, sigma: int = 9,
                  dropout: float = 0.1, vis_branch: bool = False):
         super().__init__()
-        if sigma != 9:
-            raise NotImplementedError('the Gaussian kernels are built for sigma=9 (reference default, modules.py:361)')
+        if not sigma > 0:
+            raise ValueError(f'TempMoE: sigma must be positive, got {sigma}')
         self.sigma, self.topK, self.n_experts = sigma, topK, n_experts
         if vis_branch:
             self.anorm = nn.LayerNorm(d_model)
@@ -220,7 +242,7 @@ class TempMoE(nn.Module):
         temp_w = ops.linear(o, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias)          # [B,D]
         logits = ops.linear(temp_w, self.router[0].weight, self.router[0].bias)                      # [B,K]
         raw = ops.linear(temp_w, self.gauss_pred[0].weight, self.gauss_pred[0].bias)                 # [B,2K]
-        coef, csum, ti, tp, gauss = ops.MoECoefFn.apply(logits, raw, T, K, k)
+        coef, csum, ti, tp, gauss = ops.MoECoefFn.apply(logits, raw, T, K, k, float(self.sigma))
         self.last = dict(temp_w=temp_w.detach(), router_logits=logits.detach(), topk_inds=ti, topk_probs=tp, gauss=gauss)
         # all experts, first layer, as one GEMM over the stacked streams
         w1 = torch.cat([e[0].weight for e in self.experts], dim=0)        # [K*Dh, D]

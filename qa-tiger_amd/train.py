@@ -64,6 +64,16 @@ class FlatParams:
     def numel(self) -> int:
         return sum(p.numel() for p in self.params)
 
+    def check(self) -> None:
+        """The parameters must still BE views of the flat buffer.  `model.to(...)`, `model.float()`, `load_state_dict(...,
+        assign=True)` and similar re-allocate `p.data`; the optimizer would then update memory the model no longer reads.
+        Checked (first and last parameter: two pointer reads) at the start of every step instead of failing silently."""
+        for i in (0, len(self.params) - 1):
+            p, o = self.params[i], self.offsets[i]
+            if p.data_ptr() != self.flat.data_ptr() + o * self.flat.element_size():
+                raise RuntimeError('FlatParams: a parameter no longer lives in the flat buffer (was the model moved or cast after '
+                                   'the optimizer was built?); move the model first, then build FlatParams / DataParallelStep')
+
 
 class GradSync:
     """Copy finished gradients into `flat.grad` and all-reduce them bucket by bucket.
@@ -77,6 +87,8 @@ class GradSync:
         self.flat = flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # a one-rank group normally skips the collective; tests set this to drive the RCCL path on one GPU
+        self.force_collective = False
         n = len(flat.params)
         self.bucket_of = [0] * n
         self.buckets: List[List[int]] = []        # [lo, hi, n_params]
@@ -93,6 +105,7 @@ class GradSync:
         self._seen = [False] * n
         self._works = []
         self._fired = [False] * len(self.buckets)
+        self.trace = None                         # set to a list to record ('grad', param index) / ('fire', bucket) / ('finish',) in order
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         self.begin()
@@ -106,6 +119,8 @@ class GradSync:
                 p.grad = gv                        # later accumulations (shared weights) add in place
             if not self._seen[i]:
                 self._seen[i] = True
+                if self.trace is not None:
+                    self.trace.append(('grad', i))
                 b = self.bucket_of[i]
                 self._pending[b] -= 1
                 if self._pending[b] == 0:
@@ -114,13 +129,16 @@ class GradSync:
 
     def _fire(self, b: int):
         self._fired[b] = True
-        if self.world > 1:
+        if self.trace is not None:
+            self.trace.append(('fire', b))
+        if self.world > 1 or self.force_collective:
             lo, hi, _ = self.buckets[b]
             self._works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def begin(self):
         """Call before backward: forget last step's gradients (grad=None => autograd
         hands over fresh tensors, no memset of the flat buffer needed)."""
+        self.flat.check()
         for p in self.flat.params:
             p.grad = None
         ops.grad_claims.clear()                   # first producer of a parameter's gradient this step may write in place
@@ -132,6 +150,8 @@ class GradSync:
     def finish(self):
         """Call after backward: parameters that got no gradient this step count as
         zero; flush unfinished buckets; wait for the collectives."""
+        if self.trace is not None:
+            self.trace.append(('finish',))
         for i, seen in enumerate(self._seen):
             if not seen:
                 self.flat.grad_views[i].zero_()
@@ -143,21 +163,81 @@ class GradSync:
         self._works = []
 
 
-class FusedAdam:
-    def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-8):
-        self.flat, self.lr, self.betas, self.eps = flat, lr, tuple(betas), eps
+class FusedAdam(torch.optim.Optimizer):
+    """`torch.optim.Adam(params, lr, betas, eps, weight_decay)` (reference trainutils.py:141-144) as ONE kernel over the
+    flat parameter / gradient / moment buffers.  A real `torch.optim.Optimizer`: one param group whose `lr`, `betas`,
+    `eps` and `weight_decay` are read at every `step()`, so the reference's schedulers (`StepLR`, `ReduceLROnPlateau`,
+    trainutils.py:147-182) drive it unchanged; `state_dict()` / `load_state_dict()` round-trip the moments (kept as views
+    of the flat moment buffers) and the step count in torch's own per-parameter layout."""
+
+    def __init__(self, flat: FlatParams, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError(f'FusedAdam: bad hyper-parameters lr={lr} betas={betas} eps={eps} weight_decay={weight_decay}')
+        self.flat = flat
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = 0
+        super().__init__(flat.params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._bind_state()
 
-    def step(self, grad_scale: float = 1.0):
+    def _bind_state(self):
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            n = p.numel()
+            self.state[p] = dict(step=torch.tensor(float(self.step_count)),
+                                 exp_avg=self.exp_avg[o:o + n].view(p.shape), exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape))
+
+    # the attribute spellings the rest of the repo (and round-1 callers) use
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, v: float):
+        self.param_groups[0]['lr'] = v
+
+    @property
+    def betas(self):
+        return self.param_groups[0]['betas']
+
+    @property
+    def eps(self) -> float:
+        return self.param_groups[0]['eps']
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if len(self.param_groups) != 1:
+            raise ValueError('FusedAdam updates one flat buffer: exactly one param group')
+        g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
-                       self.lr, self.betas, self.eps, grad_scale)
+                       g['lr'], g['betas'], g['eps'], grad_scale, g['weight_decay'])
+        return loss
 
     def state_dict(self) -> dict:
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr,
-                    betas=self.betas, eps=self.eps)
+        for st in self.state.values():
+            st['step'] = torch.tensor(float(self.step_count))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        super().load_state_dict(state_dict)             # torch hands back COPIES of the moments, keyed by parameter
+        steps = set()
+        with torch.no_grad():
+            for p, o in zip(self.flat.params, self.flat.offsets):
+                st, n = self.state.get(p), p.numel()
+                if not st:
+                    continue
+                self.exp_avg[o:o + n].view(p.shape).copy_(st['exp_avg'])
+                self.exp_avg_sq[o:o + n].view(p.shape).copy_(st['exp_avg_sq'])
+                steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError(f'FusedAdam keeps one step count for all parameters; the checkpoint holds {sorted(steps)}')
+        if steps:
+            self.step_count = steps.pop()
+        self._bind_state()
 
 
 class DataParallelStep:
@@ -166,11 +246,11 @@ class DataParallelStep:
     reference trainutils.py:191-194)."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.95, 0.999), eps: float = 1e-8,
-                 process_group=None, bucket_bytes: int = 32 << 20):
+                 process_group=None, bucket_bytes: int = 32 << 20, weight_decay: float = 0.0):
         self.model = model
         self.flat = FlatParams(model.parameters())
         self.sync = GradSync(self.flat, process_group, bucket_bytes)
-        self.optim = FusedAdam(self.flat, lr, betas, eps)
+        self.optim = FusedAdam(self.flat, lr, betas, eps, weight_decay)
         self.criterion = CrossEntropyLoss()
 
     def forward_backward(self, batch: Dict[str, Tensor]) -> Tensor:

@@ -1,0 +1,115 @@
+"""One rank of the data-parallel train step over RCCL (torch.distributed backend 'nccl'), GPU box only.
+
+    python tests/rccl_driver.py <rank> <world> <port>
+
+world = 1 runs on the one GPU of the test box and still drives every RCCL call of the path (the collective is forced for a
+one-rank group): `init_process_group('nccl', device_id=...)` as bench.py does it, the asynchronous bucket all-reduces issued
+from the post-accumulate-grad hooks, `work.wait()` (which orders the current stream behind RCCL's stream), the 1/world
+scaling inside the fused Adam, the per-step scalar loss all-reduce and the barrier of reference src/trainutils.py:47-79.
+world = 2 (needs two GPUs) additionally checks that both ranks end with identical weights and that the summed gradient
+equals the sum of the two local gradients.
+
+Checks, printed as one JSON line by rank 0 (exit code 0 = all true):
+  * gradients after the exchange == world x... for one rank: the local gradients of an engine without a process group;
+  * the first bucket's all-reduce is issued BEFORE backward has produced the last gradient (overlap by construction);
+  * three optimizer steps give the same weights as the local engine.
+"""
+import importlib
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main(rank: int, world: int, port: int) -> int:
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device('cuda', rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)      # "nccl" is RCCL on ROCm
+    qt = importlib.import_module('qa-tiger_amd')
+    train = importlib.import_module('qa-tiger_amd.train')
+    synth = qt.synth
+    cfg, seed = synth.CONFIG_TOY_KK, 11
+    P = synth.make_state_dict(cfg, seed)
+    full = synth.make_inputs(cfg, seed)                                   # B = 9: not divisible by 2 -> use the first 8 rows
+    B = (cfg.B // world) * world
+    full = {k: v[:B] for k, v in full.items()}
+    shard = {k: v.to(dev) for k, v in train.shard_batch(full, rank, world).items()}
+
+    def engine(bucket_bytes, with_group):
+        model = qt.QA_TIGER(**cfg.model_kwargs())
+        model.load_state_dict(P, strict=True)
+        model = model.to(dev).eval()
+        eng = qt.DataParallelStep(model, lr=1e-4, betas=(0.95, 0.999), bucket_bytes=bucket_bytes)
+        if not with_group:
+            eng.sync.world = 1                                            # purely local: no collective, no averaging
+        else:
+            eng.sync.force_collective = True                              # drive RCCL even in a one-rank group
+        return eng
+
+    ok = True
+    rep = dict(world=world)
+    local = engine(32 << 20, with_group=False)
+    local.forward_backward(shard)
+    g_local = local.flat.grad.clone()
+
+    eng = engine(64 << 10, with_group=True)                               # small buckets: several collectives per step
+    eng.sync.trace = []
+    eng.forward_backward(shard)
+    torch.cuda.synchronize()
+    g_sum = eng.flat.grad.clone()
+    trace = eng.sync.trace
+    eng.sync.trace = None
+    rep['buckets'] = len(eng.sync.buckets)
+    first_fire = next(i for i, e in enumerate(trace) if e[0] == 'fire')
+    last_grad = max(i for i, e in enumerate(trace) if e[0] == 'grad')
+    finish = next(i for i, e in enumerate(trace) if e[0] == 'finish')
+    rep['first_fire_at'], rep['last_grad_at'], rep['events'] = first_fire, last_grad, len(trace)
+    ok = ok and len(eng.sync.buckets) >= 3 and first_fire < last_grad < finish
+    fired_before_finish = sum(1 for e in trace[:finish] if e[0] == 'fire')
+    rep['buckets_fired_during_backward'] = fired_before_finish
+    ok = ok and fired_before_finish >= len(eng.sync.buckets) - 1
+
+    # SUM over ranks of the local gradients
+    ref = g_local.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    err = float((g_sum - ref).abs().max() / ref.abs().max())
+    rep['grad_exchange_rel_err'] = err
+    ok = ok and err < 1e-6
+
+    # three steps: same weights on every rank; for one rank also equal to the local engine's
+    eng.optim.step(grad_scale=1.0 / world)
+    local.optim.step()
+    for _ in range(2):
+        loss = eng.step(shard)
+        local.step(shard)
+        gv = loss.detach().clone()                                        # gather_losses, trainutils.py:60-67
+        dist.all_reduce(gv, op=dist.ReduceOp.SUM)
+        rep['mean_loss'] = gv.item() / dist.get_world_size()
+    dist.barrier()                                                        # sync_processes, trainutils.py:47-49
+    w = eng.flat.flat.clone()
+    w0 = w.clone()
+    dist.broadcast(w0, src=0)
+    rep['replica_weight_diff'] = float((w - w0).abs().max())
+    ok = ok and rep['replica_weight_diff'] == 0.0
+    if world == 1:
+        rep['vs_local_weight_diff'] = float((w - local.flat.flat).abs().max())
+        ok = ok and rep['vs_local_weight_diff'] < 1e-7
+    okt = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    ok = bool(okt.item() > 0)
+    rep['ok'] = ok
+    if rank == 0:
+        print(json.dumps(rep))
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])))

@@ -20,17 +20,52 @@ def test_library_exports_every_declared_symbol(qt):
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/qatiger.h but not exported'
     assert sorted(lib_mod.EXPORTS) == declared, 'ctypes table and header disagree'
-    assert lib.qt_version() >= 100
+    assert lib.qt_version() == lib_mod.ABI_VERSION            # a stale library is refused by load() itself
     assert isinstance(lib.qt_last_error(), bytes)
     # the product library must not link anything of the oracle or torch
     assert os.path.basename(lib_mod.LIB_PATH) == 'libqatiger_hip.so'
+
+
+def test_stale_library_is_detected_by_content_hash(qt, tmp_path, monkeypatch):
+    """load() rebuilds (or refuses) a library built from other sources: the check is a content hash of csrc/, not mtimes."""
+    lib_mod = importlib.import_module('qa-tiger_amd._lib')
+    assert open(lib_mod.HASH_PATH).read().strip() == lib_mod.source_hash()
+    monkeypatch.setattr(lib_mod, 'SOURCES', lib_mod.SOURCES[:-1])      # pretend one source file is gone: another hash
+    assert open(lib_mod.HASH_PATH).read().strip() != lib_mod.source_hash()
+
+
+def test_fused_adam_optimizer_surface_on_cpu(qt):
+    """No kernel call (no GPU here): the reference's schedulers and checkpoint code see an ordinary torch optimizer
+    (reference src/trainutils.py:141-182)."""
+    net = torch.nn.Linear(4, 3)
+    flat = qt.FlatParams(net.parameters())
+    opt = qt.FusedAdam(flat, lr=1e-3, betas=(0.95, 0.999), weight_decay=0.01)
+    assert isinstance(opt, torch.optim.Optimizer)
+    g = opt.param_groups[0]
+    assert (g['lr'], g['betas'], g['eps'], g['weight_decay']) == (1e-3, (0.95, 0.999), 1e-8, 0.01)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.1)
+    opt.step_count = 7
+    sd = opt.state_dict()
+    assert len(sd['state']) == 2 and float(sd['state'][0]['step']) == 7 and sd['state'][0]['exp_avg'].shape == (3, 4)
+    sd['state'][1]['exp_avg'] = torch.full((3,), 2.0)
+    opt2 = qt.FusedAdam(flat)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 7 and opt2.param_groups[0]['weight_decay'] == 0.01
+    assert float(opt2.exp_avg[flat.offsets[1]:flat.offsets[1] + 3].min()) == 2.0
+    assert opt2.state[flat.params[1]]['exp_avg'].data_ptr() == opt2.exp_avg[flat.offsets[1]:].data_ptr()   # views again
+    with pytest.raises(ValueError):
+        qt.FusedAdam(flat, weight_decay=-1.0)
+    net.double()
+    with pytest.raises(RuntimeError, match='flat buffer'):
+        flat.check()
+    del sched
 
 
 def test_bad_arguments_return_error_codes_without_a_gpu(qt):
     lib = importlib.import_module('qa-tiger_amd._lib').load()
     rc = lib.qt_gemm_f32(None, 0, 1, 0, 4, 4, 1.0, None, 4, None, 4, None, 4, None, None, 0, 0, None, 0, 1.0, 0.0, 0, 0, 0, 1, 0, 0, 0)
     assert rc == -2 and b'empty problem' in lib.qt_last_error()
-    rc = lib.qt_moe_router_fwd(None, None, None, 1, 1, 1, 1, None, None, None, None)
+    rc = lib.qt_moe_router_fwd(None, None, None, 1, 1, 1, 1, 9.0, None, None, None, None)
     assert rc == -2 and b'null pointer' in lib.qt_last_error()
 
 

@@ -100,6 +100,31 @@ def test_device_feeder_matches_get_items(tmp_path, dtype):
 
 
 @pytest.mark.gpu
+def test_device_feeder_slot_reuse_waits_for_the_consumer(tmp_path):
+    """The submit-next-then-take loop with NO host sync per step: while the GPU is still busy with batch i (a long
+    spin kernel queued in front of the kernel that reads it), batch i+2 is submitted into the same slot.  The read of
+    batch i must still see batch i (the slot's `free` event is recorded by that submit on the consumer's stream)."""
+    names, dirs = make_dataset(str(tmp_path), n=8, T=6, Da=128, Dv=96, P=14, Dp=64, seed=5)
+    path = str(tmp_path / 'f.qtfs')
+    fio.pack_features(names, path, dirs['vggish'], dirs['frame_ViT-L14@336px'], dirs['visual_tome14'])
+    feeder = fio.DeviceFeeder(fio.FeatureShard(path), 'cuda', max_batch=2, depth=2)
+    batches = [names[0:2], names[2:4], names[4:6], names[6:8]]
+    seen = []
+    feeder.submit(batches[0])
+    for i, cur in enumerate(batches):
+        if i + 1 < len(batches):
+            feeder.submit(batches[i + 1])
+        got = feeder.take()
+        torch.cuda._sleep(int(2.0e8))                                   # ~0.1 s of GPU time in front of the consumer kernel
+        seen.append({k: v.clone() for k, v in got.items()})            # the "train step": reads the batch late, no host sync
+    torch.cuda.synchronize()
+    for cur, got in zip(batches, seen):
+        for k in ('audio', 'video', 'patch'):
+            want = torch.from_numpy(np.stack([reference_load(dirs, nm, 1)[k] for nm in cur])).float()
+            assert torch.equal(got[k].cpu(), want), k
+
+
+@pytest.mark.gpu
 def test_cast_f16_f32_kernel_tail():
     lib = importlib.import_module('qa-tiger_amd._lib')
     for n in (1, 7, 8, 1000003):

@@ -86,7 +86,6 @@ def test_gradients_vs_reference_golden(qt, synth, name):
             assert float(np.sqrt((gr.astype(np.float64) ** 2).sum())) == pytest.approx(float(g[f'gradnorm/{pname}']), rel=GRAD_L2, abs=1e-9), pname
             flat = gr.reshape(-1)
             e = l2rel(flat[:: max(1, flat.size // 256)][:256], g[f'gradslice/{pname}'])
-            e = e / 4       # a 256-element sample of a gate-flipped row over-weights it; the norm check above is the full-tensor bound
         assert e < GRAD_L2, (pname, e)
         errs.append(e)
     assert len(errs) == len(synth.param_shapes(cfg))
@@ -156,6 +155,34 @@ def test_config2_b32_fwd_bwd_vs_oracle(qt, synth, oracle):
     """ViT-L/14 shape (T=60, D=768, K=8) at B=32: logits, arg-max, top-k order and every gradient."""
     cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 32})
     _oracle_vs_hip(qt, synth, oracle, cfg, 713, with_grads=True)
+
+
+def test_config2_full_b256_gradients_vs_oracle(qt, synth, oracle):
+    """EVERY gradient at the size the metric is quoted on (B=256, T=60, D=768, K=8): forward + CE + backward on the HIP
+    path against the CPU oracle's autograd on the same batch (fwd+bwd of the oracle: tens of seconds on the box's cores).
+    This is the bound on the split-precision BACKWARD GEMMs at the headline size."""
+    cfg = synth.CONFIG_2
+    P = synth.make_state_dict(cfg, 713)
+    inp = synth.make_inputs(cfg, 713)
+    model = qt.QA_TIGER(**cfg.model_kwargs())
+    model.load_state_dict(P, strict=True)
+    model = model.to(DEV).eval()
+    dinp = to_dev(inp)
+    out = model(dinp)['out']
+    loss = qt.CrossEntropyLoss()(out, dinp['label'])
+    loss.backward()
+    taps = {}
+    loss_r, logits_r, grads_r = oracle.forward_backward(P, inp, cfg.K, cfg.k, taps=taps)
+    for a in ('at_aggregator', 'vt_aggregator'):
+        assert torch.equal(getattr(model, a).last['topk_inds'].cpu(), taps[f'{a}.topk_inds'])
+    assert rel_err(out.detach().cpu().numpy(), logits_r.numpy()) < EXPECT
+    assert float(loss) == pytest.approx(float(loss_r), rel=1e-5)
+    errs = {n: l2rel(p.grad.cpu().numpy(), grads_r[n].numpy()) for n, p in model.named_parameters()}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f'B=256 gradient L2 rel err: median {np.median(list(errs.values())):.2e}, worst {worst}')
+    for n, e in errs.items():
+        assert e < GRAD_L2, (n, e)
+    assert float(np.median(list(errs.values()))) < GRAD_MEDIAN
 
 
 def test_config2_full_b256_forward_vs_oracle(qt, synth, oracle):

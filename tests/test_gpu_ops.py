@@ -162,6 +162,8 @@ def ref_attention(q, k, v, H):
     (6, 6, 3, 10, 10, 64),      # audio<->video cross on the stacked batch
     (8, 8, 0, 14, 14, 96),      # patch self-attention (one-wave workgroups)
     (4, 4, 0, 60, 60, 768),     # AVQ self-attention at d_h = 96
+    (3, 3, 1, 64, 64, 1024),    # the largest resident geometry at d_h = 128
+    (2, 2, 0, 60, 60, 1024),
 ])
 def test_attention_packed(ops, N, nkv, shift, Lq, Lk, E):
     H = 8
@@ -179,7 +181,11 @@ def test_attention_packed(ops, N, nkv, shift, Lq, Lk, E):
     assert rel(qkv.grad, x.grad) < 5e-5
 
 
-@pytest.mark.parametrize('N,nkv,Lq,Lk,E', [(8, 4, 10, 77, 64), (5, 5, 1, 60, 768), (7, 7, 1, 2, 64), (6, 3, 60, 77, 768)])
+@pytest.mark.parametrize('N,nkv,Lq,Lk,E', [(8, 4, 10, 77, 64), (5, 5, 1, 60, 768), (7, 7, 1, 2, 64), (6, 3, 60, 77, 768),
+                                          # the window where the MFMA BACKWARD would not fit 160 KiB of LDS (d_h >= 96, 81 <= Lk <= 128, Lq > 16):
+                                          # forward and backward must take the same (streaming) family — csrc/attn.hip attn_path
+                                          (4, 2, 60, 100, 768), (3, 3, 32, 128, 1024), (4, 4, 17, 81, 768), (2, 2, 64, 128, 1024),
+                                          (3, 3, 16, 128, 1024)])
 def test_attention_q_and_packed_kv(ops, N, nkv, Lq, Lk, E):
     H = 8
     qb = rnd(N * Lq, E, seed=22).requires_grad_(True)

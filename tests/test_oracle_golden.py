@@ -232,3 +232,45 @@ def test_tspm_oracle_matches_reference(synth, name, cfg_kw):
                 worst = max(worst, np.abs(gn.reshape(-1)[:: max(1, gn.size // 256)][:256] - ref).max() / den)
             assert np.sqrt((gn.astype(np.float64) ** 2).sum()) == pytest.approx(float(g[f'gradnorm/{n}']), rel=2e-4, abs=1e-9)
     assert worst < 2e-4
+
+
+# --------------------------------------------------------------------------- #
+# call forms the path never takes but the reference modules support (tools/make_golden.py --generality)
+# --------------------------------------------------------------------------- #
+def _kat(tag):
+    g = load_golden('generality_kats')
+    pick = lambda kind: {k.split('/', 2)[2]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f'{tag}/{kind}/')}
+    return g, pick('w'), pick('in'), pick('out'), pick('grad'), pick('din')
+
+
+def test_oracle_avq_visualize_weights(oracle):
+    """AVQCrossAttn.forward(visualize=True): outputs and the two head-averaged question-attention maps (modules.py:261-263)."""
+    _, W, I, O, _, _ = _kat('avq_vis')
+    P = {f'crs_attn.{n}': t for n, t in W.items()}
+    a, v, (aw, vw) = oracle.avq_cross_attn(P, I['audio'], I['video'], I['words'], oracle._Ctx(), visualize=True)
+    assert rel_err(a.numpy(), O['src1'].numpy()) < TOL and rel_err(v.numpy(), O['src2'].numpy()) < TOL
+    assert rel_err(aw.numpy(), O['a_weight'].numpy()) < TOL and rel_err(vw.numpy(), O['v_weight'].numpy()) < TOL
+    assert aw.shape == (3, 7, 5) and torch.allclose(aw.sum(-1), torch.ones(3, 7), atol=1e-5)
+
+
+@pytest.mark.parametrize('tag,n', [('qg_s5', 2), ('qg_s4', 1)])
+def test_oracle_qst_grounding_long_sequences(oracle, tag, n):
+    _, W, I, O, _, _ = _kat(tag)
+    P = {f'quest_grounding.{k}': t for k, t in W.items()}
+    out = oracle.qst_grounding(P, I['qst'], [I[f'data{i}'] for i in range(n)], oracle._Ctx())
+    assert rel_err(out.numpy(), O['out'].numpy()) < TOL
+
+
+@pytest.mark.parametrize('tag', ['moe_sigma5', 'moe_sigma14'])
+def test_oracle_tempmoe_sigma(oracle, tag):
+    g, W, I, O, _, _ = _kat(tag)
+    P = {f'agg.{k}': t for k, t in W.items()}
+    sub = [I['sub0'], I['sub1']] if 'sub0' in I else None
+    out = oracle.temp_moe(P, 'agg', I['qst'], I['data'], sub, 5, 3, oracle._Ctx(), sigma=float(g[f'{tag}/sigma']))
+    outs = out if isinstance(out, tuple) else (out,)
+    for i, o in enumerate(outs):
+        assert rel_err(o.numpy(), O[f'out{i}'].numpy()) < TOL
+    # and sigma matters: the default (9) must NOT reproduce these vectors
+    other = oracle.temp_moe(P, 'agg', I['qst'], I['data'], sub, 5, 3, oracle._Ctx())
+    other = other if isinstance(other, tuple) else (other,)
+    assert rel_err(other[0].numpy(), O['out0'].numpy()) > 1e-3

@@ -185,6 +185,76 @@ def block_kats(modules):
     return rec
 
 
+def generality_kats(modules):
+    """Known answers for the three call forms the path itself never takes but the reference modules support:
+    `AVQCrossAttn.forward(visualize=True)` (modules.py:261-263), `QstGrounding` over S > 3 tokens (modules.py:304-347),
+    `TempMoE(sigma != 9)` (modules.py:361, 457).  Module weights (small dims), inputs, outputs and every gradient."""
+    rec = {}
+
+    def dump(tag, mod, ins, outs, loss):
+        loss.backward()
+        for n, t in mod.state_dict().items():
+            rec[f'{tag}/w/{n}'] = t.detach().numpy().copy()
+        for n, t in ins.items():
+            rec[f'{tag}/in/{n}'] = t.detach().numpy().copy()
+            if t.grad is not None:
+                rec[f'{tag}/din/{n}'] = t.grad.numpy().copy()
+        for n, t in outs.items():
+            rec[f'{tag}/out/{n}'] = t.detach().numpy().copy()
+        for n, p in mod.named_parameters():
+            rec[f'{tag}/grad/{n}'] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+
+    def perturb(mod, g):       # non-trivial biases / LayerNorm gains so that every term is exercised
+        with torch.no_grad():
+            for n, p in mod.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+
+    D = 64
+    # 1. AVQCrossAttn visualize=True
+    g = torch.Generator().manual_seed(4001)
+    torch.manual_seed(4001)
+    m = modules.AVQCrossAttn(D, 8).eval()
+    perturb(m, g)
+    a = torch.randn(3, 7, D, generator=g).requires_grad_(True)
+    v = torch.randn(3, 7, D, generator=g).requires_grad_(True)
+    w = torch.randn(3, 5, D, generator=g).requires_grad_(True)
+    s1, s2, (aw, vw) = m(a, v, w, visualize=True)
+    dump('avq_vis', m, dict(audio=a, video=v, words=w), dict(src1=s1, src2=s2, a_weight=aw, v_weight=vw),
+         (s1 * torch.randn(s1.shape, generator=g)).sum() + (s2 * torch.randn(s2.shape, generator=g)).sum())
+    # 2. QstGrounding over S = 5 (a list of 2 + 3 tokens) and S = 4 (one tensor)
+    for tag, parts in (('qg_s5', (2, 3)), ('qg_s4', (4,))):
+        torch.manual_seed(4002)
+        m = modules.QstGrounding(D, 8).eval()
+        perturb(m, g)
+        q = torch.randn(4, D, generator=g).requires_grad_(True)
+        ds = [torch.randn(4, n, D, generator=g).requires_grad_(True) for n in parts]
+        out = m(q, ds if len(ds) > 1 else ds[0])
+        dump(tag, m, dict(qst=q, **{f'data{i}': d for i, d in enumerate(ds)}), dict(out=out),
+             (out * torch.randn(out.shape, generator=g)).sum())
+    # 3. TempMoE with sigma = 5 and sigma = 14.5, both branches
+    for tag, sigma, vis in (('moe_sigma5', 5, False), ('moe_sigma14', 14.5, True)):
+        torch.manual_seed(4003)
+        m = modules.TempMoE(D, 8, topK=3, n_experts=5, sigma=sigma, vis_branch=vis).eval()
+        perturb(m, g)
+        q = torch.randn(6, D, generator=g).requires_grad_(True)
+        d = torch.randn(6, 9, D, generator=g).requires_grad_(True)
+        ins = dict(qst=q, data=d)
+        if vis:
+            sub = [torch.randn(6, 9, D, generator=g).requires_grad_(True) for _ in range(2)]
+            ins.update(sub0=sub[0], sub1=sub[1])
+            o1, o2 = m(q, d, sub)
+            outs = dict(out0=o1, out1=o2)
+            loss = (o1 * torch.randn(o1.shape, generator=g)).sum() + (o2 * torch.randn(o2.shape, generator=g)).sum()
+        else:
+            o1 = m(q, d)
+            outs = dict(out0=o1)
+            loss = (o1 * torch.randn(o1.shape, generator=g)).sum()
+        rec[f'{tag}/sigma'] = np.array(float(sigma))
+        dump(tag, m, ins, outs, loss)
+    return rec
+
+
 def text_golden(text_cfg, B, seed, full):
     """Run the reference's own text-side CLIP modules (src/models/base/clip_base.py, pure torch) in the
     order `CLIP_TEncoder.forward` calls them (src/models/encoders.py:30-37; that file itself imports the
@@ -287,6 +357,11 @@ def main():
             print(f'{name}: loss={float(rec["loss"]):.6f} topk_gap={float(rec["topk_gap"]):.2e} -> {os.path.getsize(path) / 1024:.0f} KiB')
         return
     net, modules = import_reference()
+    if '--generality' in sys.argv:
+        path = os.path.join(OUT, 'generality_kats.npz')
+        np.savez_compressed(path, **generality_kats(modules))
+        print(f'generality_kats -> {os.path.getsize(path) / 1024:.0f} KiB')
+        return
     if '--text-only' in sys.argv or '--all' in sys.argv or len(sys.argv) == 1:
         for name, tcfg, B, full in [('text_toy', synth.TEXT_TOY, 5, True), ('text_vitl14_b4', synth.TEXT_VITL14, 4, False)]:
             rec = text_golden(tcfg, B, 713, full)
