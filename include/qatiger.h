@@ -152,6 +152,29 @@ int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long*
 int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                  int step, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay);
 
+/* ---- pre-split operands (csrc/gemm_plane.hip): the same Linear / projection GEMMs and their backward, on operands whose
+ * fp32 -> (hi, lo) fp16 split was done ONCE by a producer pass instead of inside every tile of the GEMM. ---- */
+
+/* max |x| over an fp32 [R, C] tensor (row pitch ldx elements) into the device float *amax (atomic max on the bit pattern);
+ * zero_first != 0 clears *amax first, 0 folds into an earlier maximum. */
+int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first);
+/* fp32 [R, C] -> split image: per row and per block of 32 columns one 128-byte line [32 x fp16 hi | 32 x fp16 lo] with
+ * hi = fp16(s x), lo = fp16(s x - hi); s = 2^e chosen from *amax (nullable: s = 1) so that s * amax lies in [2^13, 2^14).
+ * img: R rows of ld_img_bytes (multiple of 128, >= 4 C).  colsum (nullable): colsum[c] = sum_r x[r, c], the bias gradient of a
+ * Linear layer whose dY is being split for its dX / dW GEMMs (overwritten). */
+int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const float* amax, void* img, long ld_img_bytes,
+                 float* colsum);
+/* C[M,N] = epilogue(alpha / (s_a s_b) * op(A) op(B)) with the epilogue of qt_gemm_f32, on split images streamed to LDS by LDS-DMA.
+ *   a_kslow = 0: A image holds [M rows][K];  a_kslow = 1: [K rows][M]  (dW = dY^T X reads dY and X this way)
+ *   b_kslow = 0: B image holds [N rows][K] (nn.Linear weight layout);  b_kslow = 1: [K rows][N]
+ * a_amax / b_amax: the device floats the images were scaled by (nullable = unscaled).
+ * K must be a multiple of 32 (and M / N of a K-slow operand); returns -4 without touching C when the shape does not fit. */
+int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+               const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+               float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+               const float* mask_src, long ld_mask, float mask_scale,
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
+
 /* ---- frozen CLIP text tower (forward only) and evaluation counters ---- */
 
 /* Causal self-attention core of the text transformer: softmax(q k^T * scale + mask) v with the additive

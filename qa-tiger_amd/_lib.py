@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
-SOURCES = ['gemm.hip', 'gemm_split.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
+SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_plane.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
 ABI_VERSION = 200          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
@@ -107,6 +107,9 @@ _i, _l, _f, _u64 = C.c_int, C.c_long, C.c_float, C.c_ulonglong
 SIGNATURES = {
     'qt_gemm_f32': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _i, _l, _l, _l],
     'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _i, _l, _l, _l],
+    'qt_gemm_ps': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
+    'qt_split_f16': [_p, _p, _l, _l, _i, _p, _p, _l, _p],
+    'qt_amax_f32': [_p, _p, _l, _l, _i, _p, _i],
     'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_xattn_bwd': [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p],
     'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],

@@ -1,0 +1,527 @@
+// Pre-split GEMM: the fp32-equivalent projection GEMM on operands that were split ONCE, by their producer, into
+// 16-bit hi/lo images, streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4) with no conversion, no VALU
+// staging and no ds_write in the consumer.
+//
+// Same role as gemm_split.hip (the nn.Linear / MHA projection GEMMs of reference src/models/modules.py and their
+// backward).  gemm_split.hip converts fp32 -> (hi, lo) inside the GEMM: every activation panel is re-converted by
+// every N tile and every weight panel by every M tile (840 times at M = 215040), and the convert -> ds_write ->
+// barrier -> ds_read chain keeps the matrix pipes at ~49 % busy.  Here:
+//
+//   * SPLIT IMAGE of a row-major fp32 matrix X[R, C] (qt_split_f16 below; C a multiple of 32): for every row and
+//     every block of 32 consecutive columns one 128-byte line  [ 32 x fp16 hi | 32 x fp16 lo ],
+//         hi = fp16(s*x),  lo = fp16(s*x - hi),   s = 2^e a per-tensor power of two (optional)
+//     -> the same bytes as the fp32 tensor, and a K step of 32 reads whole 128-byte lines.
+//     With s chosen from the tensor's max |x| (qt_amax_f32) the parts sit in fp16's normal range whatever the
+//     tensor's magnitude (gradients down to 1e-9, weights of 1e-4, activations of 1e5): hi + lo carries 22
+//     significand bits of every element that matters for the sum, products are hi*hi + hi*lo + lo*hi with fp32
+//     accumulation -> fp32-equivalent in the FORWARD AND THE BACKWARD.  The epilogue multiplies by 1/(s_a*s_b).
+//   * an operand is consumed either K-contiguous ("row form": its contiguous dimension is the reduction dimension;
+//     fragments by ds_read_b128) or K-slow ("column form": dW = g^T x reads both g and x this way; fragments by the
+//     transposing ds_read_b64_tr_b16) FROM THE SAME IMAGE: no transposed copies.
+//   * 256x256 tile, BK = 32, 8 waves of 128x64, 64 KiB of LDS per stage, two stages.  Per K step a wave issues
+//     8 LDS-DMA instructions (1 KiB each), 24 ds_read_b128 (or 48 transposing reads) and 48 MFMAs
+//     (v_mfma_f32_32x32x16_f16): the matrix pipe is the only unit that is busy for the whole step.
+//     The DMA of step t+1 is issued right after the barrier that opens step t and lands while step t multiplies.
+//     LDS images are lane-linear (DMA destination = base + 16*lane), so the bank-conflict swizzle is applied to the
+//     per-lane SOURCE address and again on the fragment read (row form: 16-byte slot ^= (row>>1)&7; column form:
+//     64-byte unit ^= k&3): every fragment read is conflict-free.
+//   * the DMA is issued from inline asm: with the builtin, hipcc (ROCm 7.2) puts an `s_waitcnt vmcnt(0)` in front of
+//     the first ds_read after every DMA (it cannot tell the two LDS stages apart), which serialises load and
+//     multiply.  The waits are placed by hand: vmcnt(0) + s_barrier once per K step, one step after issue.
+//   * persistent workgroups with the XCD-aware tile walk of gemm_split.hip; the first DMA of the next tile goes out
+//     before the write-out of the current one.
+//
+// Epilogue contract = qt_gemm_x3 (bias, residual, ReLU/QuickGELU, mask, dropout, accumulate, split-K atomics).
+#include "qt_common.h"
+#include <type_traits>
+#include <utility>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define PBK 32                       // K step
+#define P_STAGE 65536                // bytes of one LDS stage: A tile 32 KiB + B tile 32 KiB
+#define P_OPER 32768
+
+struct PlaneArgs {
+    int M, N, K;
+    const char* A; long lda;         // split image of the A operand; lda = BYTES per image row
+    const char* B; long ldb;
+    float* C; long ldc;
+    float alpha;
+    const float* a_amax; const float* b_amax;   // nullable: max|x| the operand's image was scaled by (qt_split_f16)
+    const float* bias;
+    const float* add_src; long ld_add;
+    int relu;
+    const float* mask_src; long ld_mask; float mask_scale;
+    float drop_p; float inv_keep; unsigned long long drop_seed;
+    int accumulate;
+    int split_k, k_per_split, tiles_n, tiles_m;
+};
+
+// scale exponent of a tensor whose largest magnitude is `amax`: 2^e * amax lands in [2^13, 2^14) — a factor 4 under
+// fp16's largest finite value (65504) for the rounding of hi, 27 binades above the fp16 subnormal spacing for lo.
+__host__ __device__ inline float qt_plane_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;     // floor(log2(amax)) for normal floats
+    int e = 13 - ex;
+    e = e > 126 ? 126 : (e < -126 ? -126 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+
+// one LDS-DMA wave instruction: 64 lanes x 16 B from (sbase + voff[lane]) to LDS bytes [lds_addr, lds_addr + 1024).
+// lds_addr and sbase are wave-uniform (SGPRs).  M0 carries the LDS address; nothing else in this kernel uses M0.
+__device__ __forceinline__ void qt_dma16(unsigned lds_addr, const void* sbase, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+template <class F, int... Is> __device__ inline void p_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// AKS / BKS: the operand is K-slow (its image rows are k, its contiguous dimension is m / n).
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
+    constexpr int WMT = 4, WNT = 2, NWN = 4;          // wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32
+    constexpr int BM = 256, BN = 256, GM = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave - wm * NWN;
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)smem;     // LDS byte address of the dynamic array (0 here)
+
+    // ---- persistent tile walk (as gemm_split.hip): XCD-contiguous runs of tiles, M-fastest inside groups of GM M-tiles
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+    const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const long total = (long)tiles * p.split_k;
+    int m0 = 0, n0 = 0, kbeg = 0, kend = 0, ksplit = 0;
+    auto decode = [&](long w) {
+        const int t = (int)(w % tiles);
+        ksplit = (int)(w / tiles);
+        const int group = t / (GM * p.tiles_n);
+        const int gm_rows = min(GM, p.tiles_m - group * GM);
+        const int within = t - group * (GM * p.tiles_n);
+        const int tile_n = within / gm_rows;
+        m0 = (group * GM + (within - tile_n * gm_rows)) * BM;
+        n0 = tile_n * BN;
+        kbeg = ksplit * p.k_per_split;
+        kend = min(p.K, kbeg + p.k_per_split);
+    };
+
+    // ---- per-lane DMA source offsets (bytes from the operand base), 4 pieces of 1 KiB per operand per wave
+    unsigned offA[4], offB[4];
+    auto set_offsets = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave * 4 + i;                         // piece 0..31 of the 32 KiB tile
+            if (!AKS) {                                          // rows pc*8 .. pc*8+7, one 128-B line each
+                const int row = pc * 8 + (lane >> 3);
+                const int sl = (lane & 7) ^ ((row >> 1) & 7);
+                offA[i] = (unsigned)((long)min(m0 + row, p.M - 1) * p.lda + sl * 16);
+            } else {                                             // k row pc, 1 KiB = 8 blocks of 32 columns
+                const int unit = (lane >> 2) ^ (pc & 3);
+                const int blk = min((m0 >> 5) + (unit >> 1), (p.M >> 5) - 1);
+                offA[i] = (unsigned)((long)pc * p.lda + blk * 128 + (unit & 1) * 64 + (lane & 3) * 16);
+            }
+            if (!BKS) {
+                const int row = pc * 8 + (lane >> 3);
+                const int sl = (lane & 7) ^ ((row >> 1) & 7);
+                offB[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldb + sl * 16);
+            } else {
+                const int unit = (lane >> 2) ^ (pc & 3);
+                const int blk = min((n0 >> 5) + (unit >> 1), (p.N >> 5) - 1);
+                offB[i] = (unsigned)((long)pc * p.ldb + blk * 128 + (unit & 1) * 64 + (lane & 3) * 16);
+            }
+        }
+    };
+    auto dma = [&](int k0, int buf) {
+        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 >> 5) * 128;
+        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
+        const unsigned la = lds0 + buf * P_STAGE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qt_dma16(la + P_OPER + i * 1024, sb, offB[i]);
+    };
+
+    // ---- per-lane fragment read offsets inside a stage
+    // row form: row = base + 32*i + r; 16-byte slot (hl*4 + 2*s + h) ^ ((r>>1)&7)
+    // column form: lane 4q+p of 16-lane group g supplies row k = 16*s + 8*(g>>1) + 4*j + q, unit (2*b + hl) ^ q, bytes 32*(g&1) + 8*p
+    unsigned fa[4], fb[4];
+    {
+        const int x = (r >> 1) & 7;
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!AKS) fa[c] = (unsigned)((wm * 128 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);   // c = hl*2 + s
+            else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 8) * 64 + ((c ^ q) * 64));   // c = unit & 3
+            if (!BKS) fb[c] = (unsigned)(P_OPER + (wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
+            else      fb[c] = (unsigned)(P_OPER + ((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
+        }
+    }
+
+    floatx16 acc[WMT][WNT];
+    auto lds_u4 = [&](unsigned off) -> uint4 { return *reinterpret_cast<const uint4*>(smem + off); };
+    auto lds_tr = [&](unsigned off) -> uint2 {
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(lds0 + off));
+        return __builtin_bit_cast(uint2, v);
+    };
+    auto compute = [&](unsigned sbase) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 ah[WMT], al[WMT], bh[WNT], bl[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+                if (!AKS) {
+                    ah[i] = lds_u4(sbase + fa[0 * 2 + s] + i * 4096);
+                    al[i] = lds_u4(sbase + fa[1 * 2 + s] + i * 4096);
+                } else {
+                    // block i of the wave's 4: units 2i (hi), 2i+1 (lo); unit&3 = 2*(i&1) + hl, unit>>2 = i>>1
+                    const unsigned kb = sbase + (unsigned)(s * 16 * 1024 + (i >> 1) * 256);
+                    const uint2 h0 = lds_tr(kb + fa[2 * (i & 1) + 0]), h1 = lds_tr(kb + fa[2 * (i & 1) + 0] + 4096);
+                    const uint2 l0 = lds_tr(kb + fa[2 * (i & 1) + 1]), l1 = lds_tr(kb + fa[2 * (i & 1) + 1] + 4096);
+                    ah[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    al[i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                if (!BKS) {
+                    bh[j] = lds_u4(sbase + fb[0 * 2 + s] + j * 4096);
+                    bl[j] = lds_u4(sbase + fb[1 * 2 + s] + j * 4096);
+                } else {
+                    const unsigned kb = sbase + (unsigned)(s * 16 * 1024 + (j >> 1) * 256);
+                    const uint2 h0 = lds_tr(kb + fb[2 * (j & 1) + 0]), h1 = lds_tr(kb + fb[2 * (j & 1) + 0] + 4096);
+                    const uint2 l0 = lds_tr(kb + fb[2 * (j & 1) + 1]), l1 = lds_tr(kb + fb[2 * (j & 1) + 1] + 4096);
+                    bh[j] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    bl[j] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    long w = slot;
+    if (w >= total) return;
+    decode(w);
+    set_offsets();
+    int gstep = 0;                                     // K steps done by this workgroup so far: stage = gstep & 1 across tiles
+    if (kend > kbeg) dma(kbeg, 0);
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int nk = (kend - kbeg) / PBK;
+        for (int t = 0; t < nk; ++t, ++gstep) {
+            // The DMA of this step was issued one step ago (for the first step of a tile: before the previous tile's
+            // write-out, whose stores this wait drains too — a counted wait would need the exact number of stores issued
+            // after the DMA, which ragged tiles make data-dependent).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; stage (gstep+1)&1 is free
+            asm volatile("" ::: "memory");
+            if (t + 1 < nk) dma(kbeg + (t + 1) * PBK, (gstep + 1) & 1);
+            compute((unsigned)((gstep & 1) * P_STAGE));
+        }
+        // ---- this tile's output coordinates, kept for the epilogue while the NEXT tile's first DMA goes out
+        const int em0 = m0, en0 = n0;
+        const bool first_split = (ksplit == 0);
+        w += G;
+        const bool more = w < total;
+        if (more) {
+            decode(w);
+            set_offsets();
+            if (kend > kbeg) dma(kbeg, gstep & 1);     // stage gstep&1 was last read at step gstep-2; every wave has passed the barrier of step gstep-1
+        }
+        // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
+        float alpha = p.alpha;
+        if (p.a_amax) alpha /= qt_plane_scale(*p.a_amax);
+        if (p.b_amax) alpha /= qt_plane_scale(*p.b_amax);
+        const int mrow0 = em0 + wm * (WMT * 32) + 4 * h;
+        const int ncol0 = en0 + wn * (WNT * 32) + r;
+        float bias_v[WNT];
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int n = ncol0 + j * 32;
+            bias_v[j] = (p.bias && first_split && n < p.N) ? p.bias[n] : 0.f;
+        }
+        auto epilogue = [&](auto ADD, auto FULL) {
+            constexpr bool has_add = decltype(ADD)::value, full = decltype(FULL)::value;
+            const bool atomic = p.split_k > 1;
+            const int act = p.relu;
+            const bool use_add = has_add && (!atomic || first_split);
+            int ncl[WNT];
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) ncl[j] = min(ncol0 + j * 32, p.N - 1);
+            p_static_for<WMT>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+#pragma unroll
+                for (int eh = 0; eh < 2; ++eh) {
+                    float addv[8][WNT], mskv[8][WNT], oldv[8][WNT];
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int e = eh * 8 + e8;
+                        const long mc = min(mrow0 + i * 32 + (e & 3) + 8 * (e >> 2), p.M - 1);
+#pragma unroll
+                        for (int j = 0; j < WNT; ++j) {
+                            if (has_add) addv[e8][j] = use_add ? p.add_src[mc * p.ld_add + ncl[j]] : 0.f;
+                            if (full) {
+                                mskv[e8][j] = p.mask_src ? p.mask_src[mc * p.ld_mask + ncl[j]] : 1.f;
+                                oldv[e8][j] = p.accumulate ? p.C[mc * p.ldc + ncl[j]] : 0.f;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int e = eh * 8 + e8;
+                        const int m = mrow0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        if (m < p.M) {
+                            float* crow = p.C + (long)m * p.ldc + ncol0;
+                            p_static_for<WNT>([&](auto J) {
+                                constexpr int j = decltype(J)::value;
+                                if (ncol0 + j * 32 < p.N) {
+                                    float v = alpha * acc[i][j][e] + bias_v[j];
+                                    if (has_add) v += addv[e8][j];
+                                    if (atomic) { atomicAdd(crow + j * 32, v); return; }
+                                    if (act == 1) v = fmaxf(v, 0.f);
+                                    else if (act == 2) v = v / (1.0f + __expf(-1.702f * v));
+                                    if constexpr (full) {
+                                        if (p.mask_src) v = (mskv[e8][j] > 0.f) ? v * p.mask_scale : 0.f;
+                                        if (p.drop_p > 0.f)
+                                            v *= qt_drop_mult(p.drop_seed, (unsigned long long)m * (unsigned long long)p.N + (ncol0 + j * 32), p.drop_p, p.inv_keep);
+                                        v += oldv[e8][j];
+                                    }
+                                    crow[j * 32] = v;
+                                }
+                            });
+                        }
+                    }
+                }
+            });
+        };
+        if (p.mask_src || p.drop_p > 0.f || p.accumulate) {
+            if (p.add_src) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
+        } else if (p.add_src) epilogue(std::true_type{}, std::false_type{});
+        else epilogue(std::false_type{}, std::false_type{});
+        if (!more) break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 [R, C] (row pitch ldx) -> split image [R][C/32][hi 32 | lo 32] (row pitch ld_img BYTES), optional per-tensor scale from
+// a device max|x|, optional column sums (the bias gradient of a Linear layer whose dY is being split for the dW / dX GEMMs).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void qt_split8(const float4& a, const float4& b, float s, uint4& hi, uint4& lo) {
+    auto pair = [&](float x0, float x1, unsigned& ho, unsigned& lw) {
+        const f32x2 x = {x0 * s, x1 * s};
+        const f16x2 hh = __builtin_convertvector(x, f16x2);
+        const f32x2 d = x - __builtin_convertvector(hh, f32x2);
+        ho = __builtin_bit_cast(unsigned, hh);
+        lw = __builtin_bit_cast(unsigned, __builtin_convertvector(d, f16x2));
+    };
+    pair(a.x, a.y, hi.x, lo.x); pair(a.z, a.w, hi.y, lo.y); pair(b.x, b.y, hi.z, lo.z); pair(b.z, b.w, hi.w, lo.w);
+}
+
+// grid-stride over (row, group of 8 columns); consecutive lanes take consecutive groups: 32-byte reads, 16-byte writes, whole lines per 4 lanes
+__global__ __launch_bounds__(256) void qt_split_f16_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
+                                                           char* __restrict__ img, long ld_img) {
+    const float s = amax ? qt_plane_scale(*amax) : 1.0f;
+    const int g8 = C >> 3;
+    const long total = R * g8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / g8; const int c8 = (int)(idx - row * g8);
+        const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c8 * 8 + 4);
+        uint4 hi, lo;
+        qt_split8(a, b, s, hi, lo);
+        char* line = img + row * ld_img + (long)(c8 >> 2) * 128 + (c8 & 3) * 16;
+        *reinterpret_cast<uint4*>(line) = hi;
+        *reinterpret_cast<uint4*>(line + 64) = lo;
+    }
+}
+
+// the same with column sums: block = 64 column groups x 4 rows; grid.x = column strips of 512, grid.y = row chunks
+__global__ __launch_bounds__(256) void qt_split_f16_colsum_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
+                                                                  char* __restrict__ img, long ld_img, int rows_per_chunk, float* __restrict__ colsum) {
+    const float s = amax ? qt_plane_scale(*amax) : 1.0f;
+    const int c8 = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool on = c8 * 8 < C;
+    const long r_beg = (long)blockIdx.y * rows_per_chunk, r_end = min(R, r_beg + rows_per_chunk);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        for (long row = r_beg + (threadIdx.x >> 6); row < r_end; row += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c8 * 8);
+            const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c8 * 8 + 4);
+            cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w; cs[4] += b.x; cs[5] += b.y; cs[6] += b.z; cs[7] += b.w;
+            uint4 hi, lo;
+            qt_split8(a, b, s, hi, lo);
+            char* line = img + row * ld_img + (long)(c8 >> 2) * 128 + (c8 & 3) * 16;
+            *reinterpret_cast<uint4*>(line) = hi;
+            *reinterpret_cast<uint4*>(line + 64) = lo;
+        }
+    }
+    __shared__ float red[4][64][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x >> 6][threadIdx.x & 63][e] = cs[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            atomicAdd(colsum + c8 * 8 + e, (red[0][threadIdx.x][e] + red[1][threadIdx.x][e]) + (red[2][threadIdx.x][e] + red[3][threadIdx.x][e]));
+    }
+}
+
+// max |x| of an fp32 [R, C] tensor into *amax (device float, must be zeroed by the caller or hold an earlier max): non-negative
+// floats order like unsigned integers, so one atomicMax on the bit pattern per wave.  NaN / inf propagate as a huge pattern: the
+// scale helper then returns 1 and the GEMM's result is non-finite, as it would be in fp32.
+__global__ __launch_bounds__(256) void qt_amax_kernel(const float* __restrict__ x, long ldx, long R, int C, float* __restrict__ amax) {
+    const int g4 = C >> 2;
+    const long total = R * g4;
+    float m = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / g4; const int c4 = (int)(idx - row * g4);
+        const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
+    m = qt_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
+}
+
+static __global__ void qt_zero_n_kernel(float* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0.f; }
+
+extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first) {
+    QT_CHECK_ARG(x && amax && R > 0 && C > 0 && ldx >= C, "qt_amax_f32: bad arguments");
+    QT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && qt_aligned16(x), "qt_amax_f32: rows must be 16-byte aligned (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_first) hipLaunchKernelGGL(qt_zero_n_kernel, dim3(1), dim3(64), 0, st, amax, 1);
+    long blocks = (R * (C >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(qt_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax);
+    QT_CHECK_LAUNCH("qt_amax_f32");
+    return QT_OK;
+}
+
+extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const float* amax, void* img, long ld_img_bytes,
+                            float* colsum) {
+    QT_CHECK_ARG(x && img && R > 0 && C > 0 && ldx >= C, "qt_split_f16: bad arguments");
+    QT_CHECK_ARG(C % 32 == 0, "qt_split_f16: the image is made of 32-column lines (C=%d)", C);
+    QT_CHECK_ARG(ldx % 4 == 0 && qt_aligned16(x) && qt_aligned16(img) && ld_img_bytes % 128 == 0 && ld_img_bytes >= 4L * C,
+                 "qt_split_f16: alignment (ldx=%ld, ld_img=%ld)", ldx, ld_img_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (!colsum) {
+        long blocks = (R * (C >> 3) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(qt_split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax, (char*)img, ld_img_bytes);
+    } else {
+        const int strips = (C / 8 + 63) / 64;
+        long chunks = (2048 + strips - 1) / strips;                 // ~2048 workgroups
+        if (chunks > (R + 3) / 4) chunks = (R + 3) / 4;
+        const int rpc = (int)((R + chunks - 1) / chunks);
+        chunks = (R + rpc - 1) / rpc;
+        hipLaunchKernelGGL(qt_zero_n_kernel, dim3((C + 255) / 256), dim3(256), 0, st, colsum, C);
+        hipLaunchKernelGGL(qt_split_f16_colsum_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, st, x, ldx, R, C, amax,
+                           (char*)img, ld_img_bytes, rpc, colsum);
+    }
+    QT_CHECK_LAUNCH("qt_split_f16");
+    return QT_OK;
+}
+
+static bool ps_attr_done = false;
+
+// C[M,N] = epilogue(alpha/(s_a s_b) * op(A) op(B)) on split images.
+//   a_kslow = 0: A image is [M rows][K]  (K contiguous)      a_kslow = 1: A image is [K rows][M]
+//   b_kslow = 0: B image is [N rows][K]  (Linear weight)     b_kslow = 1: B image is [K rows][N]
+// Returns QT_ERR_UNSUPPORTED (without touching C) when the shape does not fit (callers then use qt_gemm_x3).
+extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                          const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                          float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+                          const float* mask_src, long ld_mask, float mask_scale,
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+    QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_ps: bad problem");
+    QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_ps: drop_p=%f", drop_p);
+    QT_CHECK_ARG(ldc >= N && lda_bytes % 128 == 0 && ldb_bytes % 128 == 0 && qt_aligned16(A) && qt_aligned16(B), "qt_gemm_ps: image pitch / alignment");
+    if (K % PBK != 0) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: K=%d is not a multiple of 32", K);
+    if ((a_kslow && M % 32) || (b_kslow && N % 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: a K-slow operand needs its width to be a multiple of 32");
+    if (M < 256 || N < 128) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: problem too small for the 256x256 tile");
+    {   // per-lane source offsets are 32-bit byte offsets from a wave-uniform base
+        const long spanA = a_kslow ? 32 * lda_bytes + 4L * M : (long)M * lda_bytes;
+        const long spanB = b_kslow ? 32 * ldb_bytes + 4L * N : (long)N * ldb_bytes;
+        if (spanA >= (1L << 32) || spanB >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: operand spans more than 4 GiB");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    PlaneArgs a;
+    a.M = M; a.N = N; a.K = K; a.A = (const char*)A; a.lda = lda_bytes; a.B = (const char*)B; a.ldb = ldb_bytes; a.C = C; a.ldc = ldc;
+    a.alpha = alpha; a.a_amax = a_amax; a.b_amax = b_amax; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
+    a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
+    const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
+    QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_ps: split_k>1 needs a linear epilogue");
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const long tiles = (long)tiles_m * tiles_n;
+    const long slots = 256;
+    a.tiles_m = tiles_m; a.tiles_n = tiles_n;
+    if (split_k <= 0) {
+        split_k = 1;
+        if (plain_epilogue && tiles < 2 * slots && K >= 16 * PBK) {      // same cost model as qt_gemm_x3
+            const long ovh = 16;
+            long maxs = K / (4 * PBK);
+            if (maxs > 64) maxs = 64;
+            long best = -1;
+            for (long s = 1; s <= maxs; ++s) {
+                const long rounds = (tiles * s + slots - 1) / slots;
+                const long ksteps = ((K + s - 1) / s + PBK - 1) / PBK;
+                const long cost = rounds * (ksteps + ovh);
+                if (best < 0 || cost < best) { best = cost; split_k = (int)s; }
+            }
+        }
+    }
+    int kps = (K + split_k - 1) / split_k;
+    kps = ((kps + PBK - 1) / PBK) * PBK;
+    split_k = (K + kps - 1) / kps;
+    a.split_k = split_k; a.k_per_split = kps;
+    if (split_k > 1 && !accumulate) {
+        hipError_t e = qt_zero_2d(C, ldc, M, N, st);
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_ps: zeroing C: %s", hipGetErrorString(e));
+    }
+    const long total_work = tiles * split_k;
+    dim3 grid((unsigned)(total_work > slots ? slots : total_work));
+    const size_t lds = 2 * P_STAGE;
+#define QT_PS(AK_, BK_)                                                                                       \
+    do {                                                                                                      \
+        auto kern = qt_gemm_ps_kernel<AK_, BK_>;                                                              \
+        if (!ps_attr_done) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                \
+    } while (0)
+    if (!ps_attr_done) {      // all four instances once (load-time cost, not per launch)
+        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ps_attr_done = true;
+    }
+    if (!a_kslow && !b_kslow) QT_PS(false, false);
+    else if (!a_kslow && b_kslow) QT_PS(false, true);
+    else if (a_kslow && !b_kslow) QT_PS(true, false);
+    else QT_PS(true, true);
+#undef QT_PS
+    QT_CHECK_LAUNCH("qt_gemm_ps");
+    return QT_OK;
+}

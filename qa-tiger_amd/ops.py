@@ -199,6 +199,81 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     return out
 
 
+# --------------------------------------------------------------------------- #
+# pre-split operands (csrc/gemm_plane.hip)
+# --------------------------------------------------------------------------- #
+class SplitImage:
+    """A GEMM operand split once into fp16 (hi, lo) lines (include/qatiger.h qt_split_f16).  `data` has the shape and
+    byte size of the fp32 tensor it was made from ([rows, cols] fp32-typed storage: an opaque byte image); `amax` is the
+    device float the image was scaled by (None = unscaled)."""
+    __slots__ = ('data', 'rows', 'cols', 'amax')
+
+    def __init__(self, data: Tensor, rows: int, cols: int, amax: Optional[Tensor]):
+        self.data, self.rows, self.cols, self.amax = data, rows, cols, amax
+
+
+def amax_of(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """max |x| as a device float (no host sync); `out` folds into an earlier maximum."""
+    x = as2d(x)
+    _dev(x)
+    fresh = out is None
+    if fresh:
+        out = torch.empty((1,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), int(fresh)), 'qt_amax_f32')
+    return out
+
+
+def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, colsum: Optional[Tensor] = None) -> SplitImage:
+    """fp32 [rows, cols] -> SplitImage.  scaled=True measures max|x| first (one extra read of x) and scales the parts into
+    fp16's normal range; pass `amax` when a producer has already measured it."""
+    x = as2d(x)
+    _dev(x, colsum)
+    R, Cc = x.shape
+    if Cc % 32:
+        raise _lib.QTError(f'split_image: {Cc} columns is not a multiple of 32')
+    if scaled and amax is None:
+        amax = amax_of(x)
+    img = torch.empty((R, Cc), device=x.device, dtype=torch.float32)
+    rc = _launch('split', 8.0 * R * Cc, (R, Cc), lambda: _lib.load().qt_split_f16(
+        _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), 4 * Cc, _ptr(colsum)))
+    _lib.check(rc, 'qt_split_f16')
+    return SplitImage(img, R, Cc, amax)
+
+
+def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: bool = False, out: Optional[Tensor] = None,
+            bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: int = 0,
+            mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
+            accumulate: bool = False, alpha: float = 1.0, split_k: int = 0) -> Optional[Tensor]:
+    """out[M,N] = epilogue(alpha * op(a) @ op(b)) on split images; returns None (out untouched) when the shape does not fit
+    the kernel (the caller then uses `gemm` on the fp32 tensors)."""
+    M, K = (a.cols, a.rows) if a_kslow else (a.rows, a.cols)
+    N, Kb = (b.cols, b.rows) if b_kslow else (b.rows, b.cols)
+    if K != Kb:
+        raise _lib.QTError(f'gemm_ps: inner dimensions differ ({K} vs {Kb})')
+    _dev(bias, add, mask_src, out)
+    if out is None:
+        out = torch.empty((M, N), device=a.data.device, dtype=torch.float32)
+    else:
+        out = out if out.dim() == 2 else out.reshape(-1, out.shape[-1])
+        assert out.shape == (M, N) and out.stride(1) == 1
+    if add is not None:
+        add = as2d(add)
+    if mask_src is not None:
+        mask_src = as2d(mask_src)
+    rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(a_kslow), int(b_kslow), 'ps'), lambda: _lib.load().qt_gemm_ps(
+        _stream(), int(a_kslow), int(b_kslow), M, N, K, float(alpha),
+        _ptr(a.data), 4 * a.cols, _ptr(a.amax), _ptr(b.data), 4 * b.cols, _ptr(b.amax),
+        _ptr(out), _ld(out), _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
+        _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k)))
+    if rc == -4:
+        if timer is not None:
+            timer.records.pop()
+        return None
+    _lib.check(rc, 'qt_gemm_ps')
+    return out
+
+
 def colsum(x: Tensor) -> Tensor:
     x = as2d(x)
     _dev(x)

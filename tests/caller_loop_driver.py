@@ -49,7 +49,9 @@ def main(wrap: str) -> int:
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(backend='nccl', init_method='env://', rank=0, world_size=1)
 
-    tcfg = synth.TEXT_TOY
+    # words = the tower's hidden states [B,L,width], quest = EOT row @ text_projection [B,embed_dim]; QA_TIGER projects both
+    # with Linear(video_dim, d_model) (net.py:122-123), so width == embed_dim == video_dim as in ViT-L/14 (768)
+    tcfg = synth.TextConfig(width=128, layers=2, heads=2, context_length=77, vocab_size=512, embed_dim=128)
     cfg = synth.PathConfig(B=6, T=6, D=64, Dv=tcfg.embed_dim, Da=16, Dp=32, P=4, L=tcfg.context_length, K=4, k=4)
     seed = 21
     P = synth.make_state_dict(cfg, seed)

@@ -1,0 +1,121 @@
+"""Pre-split GEMM (csrc/gemm_plane.hip: qt_amax_f32 / qt_split_f16 / qt_gemm_ps) against an fp64 reference of the same
+product (plain PyTorch on the CPU).  The kernel's claim is fp32-equivalence: its error against fp64 must be of the order
+of the exact-fp32 MFMA kernel's own error, for operands of ANY magnitude once they are scaled by their max |x|."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ops(qt):
+    return qt.ops
+
+
+def rnd(*shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+
+
+def l2(a, b):
+    return float((a.double().cpu() - b.double().cpu()).norm() / b.double().norm())
+
+
+def test_split_image_layout_and_colsum(ops):
+    x = rnd(70, 96, seed=1)
+    cs = torch.empty(96, device=DEV)
+    img = ops.split_image(x.to(DEV), colsum=cs)
+    raw = img.data.cpu().view(torch.float16).reshape(70, 3, 2, 32)          # [row][block][hi|lo][32]
+    hi, lo = raw[:, :, 0, :].reshape(70, 96).float(), raw[:, :, 1, :].reshape(70, 96).float()
+    assert torch.equal(hi, x.half().float())
+    assert torch.equal(lo, (x - x.half().float()).half().float())
+    assert float((hi.double() + lo.double() - x.double()).abs().max()) < 2 ** -21 * float(x.abs().max())
+    assert rel(cs, x.double().sum(0)) < 1e-6
+    # scaled: amax lands in [2^13, 2^14)
+    y = x * 1e-7
+    im2 = ops.split_image(y.to(DEV), scaled=True)
+    assert float(im2.amax.cpu()) == float(y.abs().max())
+    hi2 = im2.data.cpu().view(torch.float16).reshape(70, 3, 2, 32)[:, :, 0, :].float()
+    assert 2 ** 13 <= float(hi2.abs().max()) < 2 ** 14 + 8
+
+
+CASES = [
+    # M, N, K, a_kslow, b_kslow
+    (512, 256, 256, False, False),     # forward: x [M,K] . W[N,K]^T
+    (768, 384, 96, False, False),      # ragged N (384 = 1.5 tiles), short K
+    (300, 256, 128, False, False),     # ragged M
+    (512, 256, 256, False, True),      # dX: dY [M,K] . W[K,N]
+    (600, 320, 160, False, True),
+    (256, 256, 1024, True, True),      # dW: dY[K,M]^T . X[K,N]
+    (768, 128, 2048, True, True),
+    (320, 288, 640, True, True),       # ragged both, K-slow widths multiples of 32
+    (512, 256, 256, True, False),
+]
+
+
+@pytest.mark.parametrize('M,N,K,aks,bks', CASES)
+def test_gemm_ps_matches_fp64(ops, M, N, K, aks, bks):
+    a = rnd(*((K, M) if aks else (M, K)), seed=3)
+    b = rnd(*((K, N) if bks else (N, K)), seed=4)
+    ia, ib = ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV))
+    out = ops.gemm_ps(ia, ib, a_kslow=aks, b_kslow=bks)
+    assert out is not None
+    ref = (a.double().t() if aks else a.double()) @ (b.double() if bks else b.double().t())
+    e = rel(out, ref)
+    exact = ops.gemm(a.to(DEV), b.to(DEV), trans_a=aks, trans_b=not bks, mode='fp32')
+    e32 = rel(exact, ref)
+    print(f'{M}x{N}x{K} aks={aks} bks={bks}: ps {e:.2e}  exact-fp32 kernel {e32:.2e}')
+    assert e < 2e-6 and e < 4 * e32 + 5e-7
+
+
+def test_gemm_ps_split_k_and_epilogues(ops):
+    M, N, K = 512, 256, 4096
+    a, b = rnd(K, M, seed=5), rnd(K, N, seed=6)
+    ia, ib = ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV))
+    ref = a.double().t() @ b.double()
+    for sk in (0, 1, 4):
+        assert rel(ops.gemm_ps(ia, ib, a_kslow=True, b_kslow=True, split_k=sk), ref) < 2e-6
+    # bias + residual + ReLU, then accumulate, then alpha
+    x, w = rnd(512, 256, seed=7), rnd(256, 256, seed=8)
+    bias, res = rnd(256, seed=9), rnd(512, 256, seed=10)
+    ix, iw = ops.split_image(x.to(DEV)), ops.split_image(w.to(DEV))
+    o = ops.gemm_ps(ix, iw, bias=bias.to(DEV), add=res.to(DEV), relu=1)
+    ref = torch.relu(x.double() @ w.double().t() + bias.double() + res.double())
+    assert rel(o, ref) < 2e-6
+    acc = res.clone().to(DEV)
+    ops.gemm_ps(ix, iw, out=acc, accumulate=True, alpha=0.5)
+    assert rel(acc, res.double() + 0.5 * (x.double() @ w.double().t())) < 2e-6
+    # dropout epilogue regenerates the mask of the split-precision kernel (same seed, same element index)
+    d1 = ops.gemm_ps(ix, iw, drop_p=0.1, seed=77)
+    d2 = ops.gemm(x.to(DEV), w.to(DEV), drop_p=0.1, seed=77, mode='f16x3')
+    assert torch.equal(d1 == 0, d2 == 0) and rel(d1, d2) < 1e-5
+
+
+@pytest.mark.parametrize('sa,sb', [(1e-7, 1.0), (1e5, 1e-4), (3e-9, 2e-5), (1e3, 1e3)])
+def test_gemm_ps_scaled_operands_any_magnitude(ops, sa, sb):
+    """Gradient-like (1e-7..1e-9), tiny-weight (1e-4) and huge-activation (1e5) operands: with the per-tensor power-of-two scale
+    the result stays fp32-equivalent; WITHOUT it the same operands lose precision or overflow (which is why it exists)."""
+    M, N, K = 512, 256, 512
+    a, b = rnd(M, K, seed=11, scale=sa), rnd(N, K, seed=12, scale=sb)
+    ref = a.double() @ b.double().t()
+    ia, ib = ops.split_image(a.to(DEV), scaled=True), ops.split_image(b.to(DEV), scaled=True)
+    out = ops.gemm_ps(ia, ib)
+    e = rel(out, ref)
+    e32 = rel(ops.gemm(a.to(DEV), b.to(DEV), mode='fp32'), ref)
+    print(f'scales {sa:g} x {sb:g}: ps(scaled) {e:.2e}, exact-fp32 kernel {e32:.2e}')
+    assert e < 2e-6 and e < 4 * e32 + 5e-7
+    raw = ops.gemm_ps(ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV)))
+    e_raw = rel(raw, ref) if bool(torch.isfinite(raw).all()) else float('inf')
+    if min(sa, sb) < 1e-3 or max(sa, sb) > 6e4:
+        assert e_raw > 10 * e
+
+
+def test_gemm_ps_refuses_what_it_cannot_tile(ops):
+    a, b = rnd(128, 64, seed=13), rnd(128, 64, seed=14)
+    assert ops.gemm_ps(ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV))) is None      # M < 256: the caller falls back
