@@ -33,6 +33,7 @@
 //
 // Epilogue contract = qt_gemm_x3 (bias, residual, ReLU/QuickGELU, mask, dropout, accumulate, split-K atomics).
 #include "qt_common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -60,6 +61,7 @@ struct PlaneArgs {
     float drop_p; float inv_keep; unsigned long long drop_seed;
     int accumulate;
     int split_k, k_per_split, tiles_n, tiles_m;
+    int debug;                       // QT_PS_DEBUG (profiling probes only): 1 skip the write-out, 2 DMA only for the first step of a tile, 4 no MFMAs
 };
 
 // scale exponent of a tensor whose largest magnitude is `amax`: 2^e * amax lands in [2^13, 2^14) — a factor 4 under
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; stage (gstep+1)&1 is free
             asm volatile("" ::: "memory");
-            if (t + 1 < nk) dma(kbeg + (t + 1) * PBK, (gstep + 1) & 1);
-            compute((unsigned)((gstep & 1) * P_STAGE));
+            if (t + 1 < nk && !(p.debug & 2)) dma(kbeg + (t + 1) * PBK, (gstep + 1) & 1);
+            if (!(p.debug & 4)) compute((unsigned)((gstep & 1) * P_STAGE));
         }
         // ---- this tile's output coordinates, kept for the epilogue while the NEXT tile's first DMA goes out
         const int em0 = m0, en0 = n0;
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             set_offsets();
             if (kend > kbeg) dma(kbeg, gstep & 1);     // stage gstep&1 was last read at step gstep-2; every wave has passed the barrier of step gstep-1
         }
+        if ((p.debug & 1) && acc[0][0][0] != 12345.678f) { if (!more) break; continue; }
         // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
         float alpha = p.alpha;
         if (p.a_amax) alpha /= qt_plane_scale(*p.a_amax);
@@ -472,6 +475,7 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
     a.alpha = alpha; a.a_amax = a_amax; a.b_amax = b_amax; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QT_PS_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_ps: split_k>1 needs a linear epilogue");
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;

@@ -32,6 +32,13 @@ elif _os.environ.get('QT_GEMM', '').lower() == 'bf16x1':
     precision = {'fwd': 'bf16x1', 'bwd': 'bf16x1'}
 else:
     precision = {'fwd': 'f16x3', 'bwd': 'bf16x3'}
+# Pre-split operand pipeline (csrc/gemm_plane.hip): Linear layers whose shapes fit run on split images — the input is split once
+# (and reused by every layer that reads it and by the dW GEMM of the backward), weights are split once per optimizer step, the
+# gradient dY is measured (max|dY|), scaled into fp16's normal range and split once for the dX and dW GEMMs: fp32-equivalent
+# products (3 fp16 MFMAs on 11+11-bit parts) in the forward AND the backward.  QT_PLANE=0 keeps every GEMM on the
+# split-in-the-consumer kernels (gemm_split.hip: fp16 parts forward, bf16 parts backward).
+plane = _os.environ.get('QT_PLANE', '1') != '0' and precision['fwd'] == 'f16x3'
+weights_epoch = 0          # bumped whenever parameter memory is rewritten behind autograd's back (train.FusedAdam.step)
 _HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'bf16x1': 3, 'f16x3_t128': 16, 'bf16x3_t128': 17, 'f16x3_t256': 32, 'bf16x3_t256': 33}   # _tNNN: force a tile (A/B testing)
 
 
@@ -336,6 +343,45 @@ class GradLink:
         self.buf = None
 
 
+def _plane_ok(rows: int, n_out: int, k_in: int) -> bool:
+    """Shapes the 256x256x32 tile of qt_gemm_ps covers for all three products of a Linear layer (y, dX, dW)."""
+    return plane and rows >= 256 and rows % 32 == 0 and n_out >= 128 and n_out % 32 == 0 and k_in >= 128 and k_in % 32 == 0
+
+
+def weight_image(weight: Tensor) -> Optional[SplitImage]:
+    """Split image of a Linear weight [n_out, k_in] (or of a row slice of one, e.g. the q / kv blocks of a packed MHA
+    in-projection), scaled by the parameter's max|w| and cached on the parameter until its memory changes."""
+    base = weight._base if weight._base is not None else weight
+    if base.dim() != 2 or weight.dim() != 2 or not base.is_contiguous() or weight.stride() != base.stride():
+        return None
+    rows_b, cols = base.shape
+    if cols % 32 or weight.shape[1] != cols:
+        return None
+    key = (base._version, weights_epoch, base.data_ptr())
+    cached = getattr(base, '_qt_wimg', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = (key, split_image(base.detach(), scaled=True))
+        base._qt_wimg = cached
+    img = cached[1]
+    r0 = (weight.storage_offset() - base.storage_offset()) // cols
+    if weight.shape[0] == rows_b and r0 == 0:
+        return img
+    return SplitImage(img.data[r0:r0 + weight.shape[0]], weight.shape[0], cols, img.amax)
+
+
+def input_image(x: Tensor, x2: Tensor) -> SplitImage:
+    """Split image of an activation (x2 = the [rows, k_in] view of x), made once per tensor object: the layers that read the
+    same tensor (the three in-projections of AVQCrossAttn, ...) and the dW GEMM of the backward share it."""
+    cached = getattr(x, '_qt_img', None)
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
+        return cached[1]
+    with torch.no_grad():
+        img = split_image(x2.detach())
+    x._qt_img = ((x._version, x.data_ptr()), img)
+    return img
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, drop_p: float, seed: int,
@@ -343,8 +389,20 @@ class LinearFn(torch.autograd.Function):
         ctx.link = link
         shape = x.shape
         x2 = as2d(x)
-        y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'])
-        ctx.save_for_backward(x2, weight, y if relu else None)
+        y = None
+        ximg = wimg = None
+        if _plane_ok(x2.shape[0], weight.shape[0], weight.shape[1]):
+            wimg = weight_image(weight)
+            if wimg is not None:
+                ximg = input_image(x, x2)
+                y = gemm_ps(ximg, wimg, bias=bias, add=residual, relu=int(relu), drop_p=drop_p, seed=seed)
+        if y is None:
+            ximg = wimg = None
+            y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'])
+        # the plane path saves the input's IMAGE (same bytes) for the dW GEMM, not the fp32 rows
+        ctx.save_for_backward(x2 if ximg is None else ximg.data, weight, y if relu else None)
+        ctx.used_plane = ximg is not None
+        ctx.wimg = wimg                             # the weight's image (weights do not change between forward and backward)
         ctx.params = (weight, bias)                 # the Parameter objects themselves (saved tensors come back as new objects)
         ctx.cfg = (relu, drop_p, seed, bias is not None, residual is not None, grad_premasked, shape)
         return y.reshape(*shape[:-1], weight.shape[0])
@@ -358,23 +416,50 @@ class LinearFn(torch.autograd.Function):
             g = mask_grad(g, y if relu else None, drop_p, seed)
         dx = dw = db = dres = None
         link = ctx.link
-        if ctx.needs_input_grad[0]:
-            if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], weight.shape[1]):
-                gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True)   # dx stays None
-                link.buf = None
-            else:
-                dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
         want_db = has_bias and ctx.needs_input_grad[2]
         w_param, b_param = ctx.params
-        if ctx.needs_input_grad[1]:
-            if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
+        if ctx.used_plane:
+            # dY: one max|dY| pass, one split pass (which also sums the columns = the bias gradient); both GEMMs then stream the image
+            n_out, k_in = weight.shape
+            if want_db:
                 bgv = _claim_grad_view(b_param)
-                db = bgv[:] if bgv is not None else torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
-            wgv = _claim_grad_view(w_param)
-            dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db,
-                      out=None if wgv is None else wgv[:])                                   # [N_out, K_in] = g^T x
-        elif want_db:
-            db = colsum(g)
+                db = bgv[:] if bgv is not None else torch.empty((n_out,), device=g.device, dtype=torch.float32)
+            gimg = split_image(g, scaled=True, colsum=db)
+            wimg = ctx.wimg
+            ximg = SplitImage(x2, x2.shape[0], x2.shape[1], None)
+            if ctx.needs_input_grad[0]:
+                if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], k_in):
+                    if gemm_ps(gimg, wimg, b_kslow=True, out=link.buf, accumulate=True) is None:
+                        raise _lib.QTError('qt_gemm_ps refused a dX shape its forward accepted')
+                    link.buf = None                     # dx stays None
+                else:
+                    dx = gemm_ps(gimg, wimg, b_kslow=True)
+                    if dx is None:
+                        raise _lib.QTError('qt_gemm_ps refused a dX shape its forward accepted')
+                    dx = dx.reshape(shape)
+            if ctx.needs_input_grad[1]:
+                wgv = _claim_grad_view(w_param)
+                dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:])
+                if dw is None:
+                    raise _lib.QTError('qt_gemm_ps refused a dW shape its forward accepted')
+                if wgv is not None:
+                    dw = wgv[:]
+        else:
+            if ctx.needs_input_grad[0]:
+                if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], weight.shape[1]):
+                    gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True)   # dx stays None
+                    link.buf = None
+                else:
+                    dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
+            if ctx.needs_input_grad[1]:
+                if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
+                    bgv = _claim_grad_view(b_param)
+                    db = bgv[:] if bgv is not None else torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
+                wgv = _claim_grad_view(w_param)
+                dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db,
+                          out=None if wgv is None else wgv[:])                                   # [N_out, K_in] = g^T x
+            elif want_db:
+                db = colsum(g)
         if has_res and ctx.needs_input_grad[6]:
             dres = g.reshape(*shape[:-1], weight.shape[0]) if not (relu or drop_p > 0.0) else None
             if dres is None:

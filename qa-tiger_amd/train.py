@@ -215,6 +215,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
                        g['lr'], g['betas'], g['eps'], grad_scale, g['weight_decay'])
+        ops.weights_epoch += 1                          # parameter memory rewritten by a raw kernel: cached weight images are stale
         return loss
 
     def state_dict(self) -> dict:
