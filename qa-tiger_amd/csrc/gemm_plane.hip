@@ -44,8 +44,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 #define PBK 32                       // K step
-#define P_STAGE 65536                // bytes of one LDS stage: A tile 32 KiB + B tile 32 KiB
-#define P_OPER 32768
+#define P_OPER 32768                 // one operand tile of a K step: 256 rows (or 32 k-rows x 256 columns) x 128 B
+#define P_A_STAGES 3                 // A (the activation / gradient operand, streamed from HBM) is prefetched TWO steps ahead,
+#define P_B_BASE (P_A_STAGES * P_OPER)   // B (weights: L2 / Infinity-Cache resident) one step ahead: 3 + 2 tiles = all 160 KiB of LDS
+#define P_LDS_BYTES (P_B_BASE + 2 * P_OPER)
 
 struct PlaneArgs {
     int M, N, K;
@@ -145,14 +147,17 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             }
         }
     };
-    auto dma = [&](int k0, int buf) {
+    auto dma_a = [&](int k0, int stage) {
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 >> 5) * 128;
-        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
-        const unsigned la = lds0 + buf * P_STAGE + wave * 4096;
+        const unsigned la = lds0 + stage * P_OPER + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
+    };
+    auto dma_b = [&](int k0, int stage) {
+        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
+        const unsigned lb = lds0 + P_B_BASE + stage * P_OPER + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qt_dma16(la + P_OPER + i * 1024, sb, offB[i]);
+        for (int i = 0; i < 4; ++i) qt_dma16(lb + i * 1024, sb, offB[i]);
     };
 
     // ---- per-lane fragment read offsets inside a stage
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         for (int c = 0; c < 4; ++c) {
             if (!AKS) fa[c] = (unsigned)((wm * 128 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);   // c = hl*2 + s
             else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 8) * 64 + ((c ^ q) * 64));   // c = unit & 3
-            if (!BKS) fb[c] = (unsigned)(P_OPER + (wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
-            else      fb[c] = (unsigned)(P_OPER + ((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
+            if (!BKS) fb[c] = (unsigned)((wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
+            else      fb[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
         }
     }
 
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(lds0 + off));
         return __builtin_bit_cast(uint2, v);
     };
-    auto compute = [&](unsigned sbase) {
+    auto compute = [&](unsigned sbase, unsigned sbase_b) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint4 ah[WMT], al[WMT], bh[WNT], bl[WNT];
@@ -198,10 +203,10 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
                 if (!BKS) {
-                    bh[j] = lds_u4(sbase + fb[0 * 2 + s] + j * 4096);
-                    bl[j] = lds_u4(sbase + fb[1 * 2 + s] + j * 4096);
+                    bh[j] = lds_u4(sbase_b + fb[0 * 2 + s] + j * 4096);
+                    bl[j] = lds_u4(sbase_b + fb[1 * 2 + s] + j * 4096);
                 } else {
-                    const unsigned kb = sbase + (unsigned)(s * 16 * 1024 + (j >> 1) * 256);
+                    const unsigned kb = sbase_b + (unsigned)(s * 16 * 1024 + (j >> 1) * 256);
                     const uint2 h0 = lds_tr(kb + fb[2 * (j & 1) + 0]), h1 = lds_tr(kb + fb[2 * (j & 1) + 0] + 4096);
                     const uint2 l0 = lds_tr(kb + fb[2 * (j & 1) + 1]), l1 = lds_tr(kb + fb[2 * (j & 1) + 1] + 4096);
                     bh[j] = make_uint4(h0.x, h0.y, h1.x, h1.y);
@@ -223,8 +228,19 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     if (w >= total) return;
     decode(w);
     set_offsets();
-    int gstep = 0;                                     // K steps done by this workgroup so far: stage = gstep & 1 across tiles
-    if (kend > kbeg) dma(kbeg, 0);
+    if (p.debug & 8) {                                 // probe: de-synchronise the CUs' tile phases (write-out bursts, DMA bursts)
+        const int d = (int)((blockIdx.x >> 3) & 7) * ((kend - kbeg) / PBK);
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(48);
+    }
+    // Stages are addressed by running step counters that continue across tiles: A step g lives in stage g % 3, B step g in g & 1.
+    int sa_cur = 0, gb = 0;                            // A stage of the current step; B step parity
+    auto nxt3 = [](int s) { return s == P_A_STAGES - 1 ? 0 : s + 1; };
+    {   // first tile: A(0), A(1), B(0)
+        const int nk0 = (kend - kbeg) / PBK;
+        dma_a(kbeg, sa_cur);
+        if (nk0 > 1) dma_a(kbeg + PBK, nxt3(sa_cur));
+        dma_b(kbeg, gb & 1);
+    }
     for (;;) {
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
@@ -233,15 +249,22 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         const int nk = (kend - kbeg) / PBK;
-        for (int t = 0; t < nk; ++t, ++gstep) {
-            // The DMA of this step was issued one step ago (for the first step of a tile: before the previous tile's
-            // write-out, whose stores this wait drains too — a counted wait would need the exact number of stores issued
-            // after the DMA, which ragged tiles make data-dependent).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; stage (gstep+1)&1 is free
+        for (int t = 0; t < nk; ++t) {
+            // Issue order is B(t+1) then A(t+2) at every step, so when step t opens the only younger transfers than the ones it
+            // reads (A(t): two steps old, B(t): one step old) are the 4 pieces of A(t+1) — if that was issued at all.  The first
+            // step of a tile also drains the previous tile's write-out (in-order counter; a counted wait would need the exact
+            // number of stores, which ragged tiles make data-dependent).
+            if (t > 0 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
-            if (t + 1 < nk && !(p.debug & 2)) dma(kbeg + (t + 1) * PBK, (gstep + 1) & 1);
-            if (!(p.debug & 4)) compute((unsigned)((gstep & 1) * P_STAGE));
+            if (!(p.debug & 2)) {
+                if (t + 1 < nk) dma_b(kbeg + (t + 1) * PBK, (gb + 1) & 1);
+                if (t + 2 < nk) dma_a(kbeg + (t + 2) * PBK, nxt3(nxt3(sa_cur)));
+            }
+            if (!(p.debug & 4)) compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER));
+            sa_cur = nxt3(sa_cur);
+            ++gb;
         }
         // ---- this tile's output coordinates, kept for the epilogue while the NEXT tile's first DMA goes out
         const int em0 = m0, en0 = n0;
@@ -251,7 +274,12 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         if (more) {
             decode(w);
             set_offsets();
-            if (kend > kbeg) dma(kbeg, gstep & 1);     // stage gstep&1 was last read at step gstep-2; every wave has passed the barrier of step gstep-1
+            // next tile's A(0), A(1), B(0): their stages were last read at steps g-2, g-1, g-1 of the running count, and every wave
+            // has passed the barrier of step g (the last one of this tile), i.e. has finished multiplying step g-1
+            const int nk1 = (kend - kbeg) / PBK;
+            dma_a(kbeg, sa_cur);
+            if (nk1 > 1) dma_a(kbeg + PBK, nxt3(sa_cur));
+            dma_b(kbeg, gb & 1);
         }
         if ((p.debug & 1) && acc[0][0][0] != 12345.678f) { if (!more) break; continue; }
         // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
@@ -360,35 +388,100 @@ __global__ __launch_bounds__(256) void qt_split_f16_kernel(const float* __restri
         *reinterpret_cast<uint4*>(line + 64) = lo;
     }
 }
-
-// the same with column sums: block = 64 column groups x 4 rows; grid.x = column strips of 512, grid.y = row chunks
-__global__ __launch_bounds__(256) void qt_split_f16_colsum_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
-                                                                  char* __restrict__ img, long ld_img, int rows_per_chunk, float* __restrict__ colsum) {
+// dense rows (ldx == C, image pitch == 4 C): the tensor is one flat run of 8-element groups and the image one flat run of lines,
+// so there is no index arithmetic; four independent groups per thread per trip keep 128 B of loads in flight per lane
+__global__ __launch_bounds__(256) void qt_split_f16_flat_kernel(const float* __restrict__ x, long n8, const float* __restrict__ amax,
+                                                                char* __restrict__ img) {
     const float s = amax ? qt_plane_scale(*amax) : 1.0f;
-    const int c8 = blockIdx.x * 64 + (threadIdx.x & 63);
-    const bool on = c8 * 8 < C;
-    const long r_beg = (long)blockIdx.y * rows_per_chunk, r_end = min(R, r_beg + rows_per_chunk);
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (on) {
-        for (long row = r_beg + (threadIdx.x >> 6); row < r_end; row += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c8 * 8);
-            const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c8 * 8 + 4);
-            cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w; cs[4] += b.x; cs[5] += b.y; cs[6] += b.z; cs[7] += b.w;
+    const long stride = (long)gridDim.x * 256;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; idx + 3 * stride < n8; idx += 4 * stride) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(x + (idx + u * stride) * 8);
+            b[u] = *reinterpret_cast<const float4*>(x + (idx + u * stride) * 8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = idx + u * stride;
             uint4 hi, lo;
-            qt_split8(a, b, s, hi, lo);
-            char* line = img + row * ld_img + (long)(c8 >> 2) * 128 + (c8 & 3) * 16;
+            qt_split8(a[u], b[u], s, hi, lo);
+            char* line = img + (i >> 2) * 128 + (i & 3) * 16;
             *reinterpret_cast<uint4*>(line) = hi;
             *reinterpret_cast<uint4*>(line + 64) = lo;
         }
     }
-    __shared__ float red[4][64][8];
+    for (; idx < n8; idx += stride) {
+        const float4 a = *reinterpret_cast<const float4*>(x + idx * 8);
+        const float4 b = *reinterpret_cast<const float4*>(x + idx * 8 + 4);
+        uint4 hi, lo;
+        qt_split8(a, b, s, hi, lo);
+        char* line = img + (idx >> 2) * 128 + (idx & 3) * 16;
+        *reinterpret_cast<uint4*>(line) = hi;
+        *reinterpret_cast<uint4*>(line + 64) = lo;
+    }
+}
+
+// the same with column sums: block = 32 column groups (256 columns, 1 KiB of a row) x 8 rows; grid.x = column strips, grid.y = row
+// chunks.  A thread keeps its 8 columns, walks the chunk's rows 8 apart with four rows of loads in flight, and the block's 8 row
+// lanes meet in LDS before one atomic per column.
+#define QT_SPC_TX 32
+#define QT_SPC_TY 8
+__global__ __launch_bounds__(256) void qt_split_f16_colsum_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
+                                                                  char* __restrict__ img, long ld_img, int rows_per_chunk, float* __restrict__ colsum) {
+    const float s = amax ? qt_plane_scale(*amax) : 1.0f;
+    const int tx = threadIdx.x & (QT_SPC_TX - 1), ty = threadIdx.x / QT_SPC_TX;
+    const int c8 = blockIdx.x * QT_SPC_TX + tx;
+    const bool on = c8 * 8 < C;
+    const long r_beg = (long)blockIdx.y * rows_per_chunk, r_end = min(R, r_beg + rows_per_chunk);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        const float* xc = x + c8 * 8;
+        char* ic = img + (long)(c8 >> 2) * 128 + (c8 & 3) * 16;
+        long row = r_beg + ty;
+        for (; row + 3 * QT_SPC_TY < r_end; row += 4 * QT_SPC_TY) {
+            float4 a[4], b[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x >> 6][threadIdx.x & 63][e] = cs[e];
+            for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const float4*>(xc + (row + u * QT_SPC_TY) * ldx);
+                b[u] = *reinterpret_cast<const float4*>(xc + (row + u * QT_SPC_TY) * ldx + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cs[0] += a[u].x; cs[1] += a[u].y; cs[2] += a[u].z; cs[3] += a[u].w; cs[4] += b[u].x; cs[5] += b[u].y; cs[6] += b[u].z; cs[7] += b[u].w;
+                uint4 hi, lo;
+                qt_split8(a[u], b[u], s, hi, lo);
+                char* line = ic + (row + u * QT_SPC_TY) * ld_img;
+                *reinterpret_cast<uint4*>(line) = hi;
+                *reinterpret_cast<uint4*>(line + 64) = lo;
+            }
+        }
+        for (; row < r_end; row += QT_SPC_TY) {
+            const float4 a = *reinterpret_cast<const float4*>(xc + row * ldx);
+            const float4 b = *reinterpret_cast<const float4*>(xc + row * ldx + 4);
+            cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w; cs[4] += b.x; cs[5] += b.y; cs[6] += b.z; cs[7] += b.w;
+            uint4 hi, lo;
+            qt_split8(a, b, s, hi, lo);
+            char* line = ic + row * ld_img;
+            *reinterpret_cast<uint4*>(line) = hi;
+            *reinterpret_cast<uint4*>(line + 64) = lo;
+        }
+    }
+    __shared__ float red[QT_SPC_TY][QT_SPC_TX][9];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx][e] = cs[e];
     __syncthreads();
-    if (threadIdx.x < 64 && on) {
+    // 256 threads = 32 column groups x 8 columns: thread t sums column (t>>3 group, t&7 element) over the 8 row lanes
+    {
+        const int gx = threadIdx.x >> 3, e = threadIdx.x & 7;
+        const int col = (blockIdx.x * QT_SPC_TX + gx) * 8 + e;
+        if (col < C) {
+            float v = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            atomicAdd(colsum + c8 * 8 + e, (red[0][threadIdx.x][e] + red[1][threadIdx.x][e]) + (red[2][threadIdx.x][e] + red[3][threadIdx.x][e]));
+            for (int y = 0; y < QT_SPC_TY; ++y) v += red[y][gx][e];
+            atomicAdd(colsum + col, v);
+        }
     }
 }
 
@@ -407,6 +500,28 @@ __global__ __launch_bounds__(256) void qt_amax_kernel(const float* __restrict__ 
     m = qt_wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
 }
+// dense rows: one flat run of float4s, eight independent loads per thread per trip
+__global__ __launch_bounds__(256) void qt_amax_flat_kernel(const float* __restrict__ x, long n4, float* __restrict__ amax) {
+    const long stride = (long)gridDim.x * 256;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    float m0 = 0.f, m1 = 0.f;
+    for (; idx + 7 * stride < n4; idx += 8 * stride) {
+        float4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = reinterpret_cast<const float4*>(x)[idx + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(a[u].x), fabsf(a[u].y))), fmaxf(fabsf(a[u].z), fabsf(a[u].w)));
+            m1 = fmaxf(fmaxf(m1, fmaxf(fabsf(a[u + 1].x), fabsf(a[u + 1].y))), fmaxf(fabsf(a[u + 1].z), fabsf(a[u + 1].w)));
+        }
+    }
+    for (; idx < n4; idx += stride) {
+        const float4 a = reinterpret_cast<const float4*>(x)[idx];
+        m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
+    const float m = qt_wave_max(fmaxf(m0, m1));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
+}
 
 static __global__ void qt_zero_n_kernel(float* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0.f; }
 
@@ -415,9 +530,12 @@ extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C
     QT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && qt_aligned16(x), "qt_amax_f32: rows must be 16-byte aligned (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
     if (zero_first) hipLaunchKernelGGL(qt_zero_n_kernel, dim3(1), dim3(64), 0, st, amax, 1);
-    long blocks = (R * (C >> 2) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(qt_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax);
+    const long n4 = R * (C >> 2);
+    long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (ldx == C) hipLaunchKernelGGL(qt_amax_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n4, amax);
+    else hipLaunchKernelGGL(qt_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax);
     QT_CHECK_LAUNCH("qt_amax_f32");
     return QT_OK;
 }
@@ -430,14 +548,20 @@ extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int 
                  "qt_split_f16: alignment (ldx=%ld, ld_img=%ld)", ldx, ld_img_bytes);
     hipStream_t st = (hipStream_t)stream;
     if (!colsum) {
-        long blocks = (R * (C >> 3) + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(qt_split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax, (char*)img, ld_img_bytes);
+        const long n8 = R * (C >> 3);
+        long blocks = (n8 + 256 * 4 - 1) / (256 * 4);
+        if (blocks > 8192) blocks = 8192;
+        if (blocks < 1) blocks = 1;
+        if (ldx == C && ld_img_bytes == 4L * C)
+            hipLaunchKernelGGL(qt_split_f16_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n8, amax, (char*)img);
+        else
+            hipLaunchKernelGGL(qt_split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax, (char*)img, ld_img_bytes);
     } else {
-        const int strips = (C / 8 + 63) / 64;
-        long chunks = (2048 + strips - 1) / strips;                 // ~2048 workgroups
-        if (chunks > (R + 3) / 4) chunks = (R + 3) / 4;
-        const int rpc = (int)((R + chunks - 1) / chunks);
+        const int strips = (C / 8 + QT_SPC_TX - 1) / QT_SPC_TX;
+        long chunks = (4096 + strips - 1) / strips;                 // ~4096 workgroups
+        if (chunks > (R + 31) / 32) chunks = (R + 31) / 32;
+        if (chunks < 1) chunks = 1;
+        const int rpc = (int)((((R + chunks - 1) / chunks) + 31) / 32 * 32);
         chunks = (R + rpc - 1) / rpc;
         hipLaunchKernelGGL(qt_zero_n_kernel, dim3((C + 255) / 256), dim3(256), 0, st, colsum, C);
         hipLaunchKernelGGL(qt_split_f16_colsum_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, st, x, ldx, R, C, amax,
@@ -507,7 +631,7 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
     }
     const long total_work = tiles * split_k;
     dim3 grid((unsigned)(total_work > slots ? slots : total_work));
-    const size_t lds = 2 * P_STAGE;
+    const size_t lds = P_LDS_BYTES;
 #define QT_PS(AK_, BK_)                                                                                       \
     do {                                                                                                      \
         auto kern = qt_gemm_ps_kernel<AK_, BK_>;                                                              \

@@ -99,8 +99,12 @@ def main(rank: int, world: int, port: int) -> int:
     rep['replica_weight_diff'] = float((w - w0).abs().max())
     ok = ok and rep['replica_weight_diff'] == 0.0
     if world == 1:
-        rep['vs_local_weight_diff'] = float((w - local.flat.flat).abs().max())
-        ok = ok and rep['vs_local_weight_diff'] < 1e-7
+        # Adam turns any gradient >> eps into a full lr step, so elements whose true gradient is zero (pure rounding noise, e.g. an
+        # MHA key bias) may move by up to 3 x lr in either engine; everything else must agree to rounding
+        d = (w - local.flat.flat).abs()
+        rep['vs_local_weight_diff_max'], rep['vs_local_weight_diff_median'] = float(d.max()), float(d.median())
+        rep['vs_local_frac_above_1e-6'] = float((d > 1e-6).float().mean())
+        ok = ok and float(d.max()) <= 3.5e-4 and float(d.median()) < 1e-7 and rep['vs_local_frac_above_1e-6'] < 0.02
     okt = torch.tensor([1.0 if ok else 0.0], device=dev)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)
     ok = bool(okt.item() > 0)
