@@ -89,7 +89,10 @@ template <class F, int... Is> __device__ inline void p_static_for_impl(F&& f, st
 template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // AKS / BKS: the operand is K-slow (its image rows are k, its contiguous dimension is m / n).
-template <bool AKS, bool BKS>
+// SWAP: the MFMAs take (B fragment, A fragment), i.e. each 32x32 accumulator holds C^T: a lane then owns FOUR CONSECUTIVE COLUMNS
+// of one row of C per register quad, and the write-out (and every epilogue operand) moves as 16-byte vectors — 32 stores per lane
+// instead of 128.  Split-K launches keep the plain orientation: their fp32 atomics run at full rate only on 128-byte row segments.
+template <bool AKS, bool BKS, bool SWAP>
 __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     constexpr int WMT = 4, WNT = 2, NWN = 4;          // wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32
     constexpr int BM = 256, BN = 256, GM = 4;
@@ -153,6 +156,14 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
+    auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
+        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 >> 5) * 128;
+        qt_dma16(lds0 + stage * P_OPER + wave * 4096 + i * 1024, sa, offA[i]);
+    };
+    auto dma_b1 = [&](int k0, int stage, int i) {
+        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
+        qt_dma16(lds0 + P_B_BASE + stage * P_OPER + wave * 4096 + i * 1024, sb, offB[i]);
+    };
     auto dma_b = [&](int k0, int stage) {
         const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
         const unsigned lb = lds0 + P_B_BASE + stage * P_OPER + wave * 4096;
@@ -182,46 +193,60 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(lds0 + off));
         return __builtin_bit_cast(uint2, v);
     };
-    auto compute = [&](unsigned sbase, unsigned sbase_b) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 ah[WMT], al[WMT], bh[WNT], bl[WNT];
-#pragma unroll
-            for (int i = 0; i < WMT; ++i) {
-                if (!AKS) {
-                    ah[i] = lds_u4(sbase + fa[0 * 2 + s] + i * 4096);
-                    al[i] = lds_u4(sbase + fa[1 * 2 + s] + i * 4096);
-                } else {
-                    // block i of the wave's 4: units 2i (hi), 2i+1 (lo); unit&3 = 2*(i&1) + hl, unit>>2 = i>>1
-                    const unsigned kb = sbase + (unsigned)(s * 16 * 1024 + (i >> 1) * 256);
-                    const uint2 h0 = lds_tr(kb + fa[2 * (i & 1) + 0]), h1 = lds_tr(kb + fa[2 * (i & 1) + 0] + 4096);
-                    const uint2 l0 = lds_tr(kb + fa[2 * (i & 1) + 1]), l1 = lds_tr(kb + fa[2 * (i & 1) + 1] + 4096);
-                    ah[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    al[i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                }
+    // One K step = 8 segments (k16 half s, A row tile i): [fragments of the NEXT segment] -> [one LDS-DMA piece of a later step]
+    // -> [6 MFMAs of this segment].  The DMA issue (60-185 cycles of the wave's issue stream each) sits between MFMA groups
+    // instead of in one block after the barrier, where both waves of a SIMD would stall the matrix pipe together.
+    auto compute = [&](unsigned sbase, unsigned sbase_b, auto&& issue) {
+        uint4 ah[2], al[2], bh[2][WNT], bl[2][WNT];
+        auto load_a = [&](int s, int i, uint4& xh, uint4& xl) {
+            if (!AKS) {
+                xh = lds_u4(sbase + fa[0 * 2 + s] + i * 4096);
+                xl = lds_u4(sbase + fa[1 * 2 + s] + i * 4096);
+            } else {
+                // block i of the wave's 4: units 2i (hi), 2i+1 (lo); unit&3 = 2*(i&1) + hl, unit>>2 = i>>1
+                const unsigned kb = sbase + (unsigned)(s * 16 * 1024 + (i >> 1) * 256);
+                const uint2 h0 = lds_tr(kb + fa[2 * (i & 1) + 0]), h1 = lds_tr(kb + fa[2 * (i & 1) + 0] + 4096);
+                const uint2 l0 = lds_tr(kb + fa[2 * (i & 1) + 1]), l1 = lds_tr(kb + fa[2 * (i & 1) + 1] + 4096);
+                xh = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                xl = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
+        };
+        auto load_b = [&](int s, uint4* xh, uint4* xl) {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
                 if (!BKS) {
-                    bh[j] = lds_u4(sbase_b + fb[0 * 2 + s] + j * 4096);
-                    bl[j] = lds_u4(sbase_b + fb[1 * 2 + s] + j * 4096);
+                    xh[j] = lds_u4(sbase_b + fb[0 * 2 + s] + j * 4096);
+                    xl[j] = lds_u4(sbase_b + fb[1 * 2 + s] + j * 4096);
                 } else {
                     const unsigned kb = sbase_b + (unsigned)(s * 16 * 1024 + (j >> 1) * 256);
                     const uint2 h0 = lds_tr(kb + fb[2 * (j & 1) + 0]), h1 = lds_tr(kb + fb[2 * (j & 1) + 0] + 4096);
                     const uint2 l0 = lds_tr(kb + fb[2 * (j & 1) + 1]), l1 = lds_tr(kb + fb[2 * (j & 1) + 1] + 4096);
-                    bh[j] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    bl[j] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    xh[j] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    xl[j] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-#pragma unroll
-                for (int j = 0; j < WNT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bl[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
-                }
-        }
+        };
+        auto mm = [&](const uint4& x, const uint4& y, floatx16 c) {
+            if (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, y), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+            else      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+        };
+        load_b(0, bh[0], bl[0]);
+        load_a(0, 0, ah[0], al[0]);
+        p_static_for<8>([&](auto SEG) {
+            constexpr int seg = decltype(SEG)::value, s = seg >> 2, i = seg & 3, cur = seg & 1;
+            if constexpr (seg + 1 < 8) {
+                constexpr int s1 = (seg + 1) >> 2, i1 = (seg + 1) & 3;
+                if constexpr (i1 == 0) load_b(s1, bh[s1], bl[s1]);
+                load_a(s1, i1, ah[cur ^ 1], al[cur ^ 1]);
+            }
+            issue(SEG);
+            p_static_for<WNT>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                acc[i][j] = mm(al[cur], bh[s][j], acc[i][j]);
+                acc[i][j] = mm(ah[cur], bl[s][j], acc[i][j]);
+                acc[i][j] = mm(ah[cur], bh[s][j], acc[i][j]);
+            });
+        });
     };
 
     long w = slot;
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     set_offsets();
     if (p.debug & 8) {                                 // probe: de-synchronise the CUs' tile phases (write-out bursts, DMA bursts)
         const int d = (int)((blockIdx.x >> 3) & 7) * ((kend - kbeg) / PBK);
-        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(48);
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(6);       // ~384 cycles x K steps x (0..7) = 0..7/8 of a tile
     }
     // Stages are addressed by running step counters that continue across tiles: A step g lives in stage g % 3, B step g in g & 1.
     int sa_cur = 0, gb = 0;                            // A stage of the current step; B step parity
@@ -258,11 +283,16 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
-            if (!(p.debug & 2)) {
-                if (t + 1 < nk) dma_b(kbeg + (t + 1) * PBK, (gb + 1) & 1);
-                if (t + 2 < nk) dma_a(kbeg + (t + 2) * PBK, nxt3(nxt3(sa_cur)));
-            }
-            if (!(p.debug & 4)) compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER));
+            const bool do_b = (t + 1 < nk) && !(p.debug & 2), do_a = (t + 2 < nk) && !(p.debug & 2);
+            const int kb1 = kbeg + (t + 1) * PBK, ka2 = kbeg + (t + 2) * PBK;
+            const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
+            auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), pieces 4-7: A(t+2) — this order is what vmcnt(4) counts on
+                constexpr int seg = decltype(SEG)::value;
+                if constexpr (seg < 4) { if (do_b) dma_b1(kb1, stb, seg); }
+                else { if (do_a) dma_a1(ka2, sta, seg - 4); }
+            };
+            if (!(p.debug & 4)) compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
+            else p_static_for<8>([&](auto SEG) { issue(SEG); });
             sa_cur = nxt3(sa_cur);
             ++gb;
         }
@@ -348,10 +378,74 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
                 }
             });
         };
-        if (p.mask_src || p.drop_p > 0.f || p.accumulate) {
-            if (p.add_src) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
-        } else if (p.add_src) epilogue(std::true_type{}, std::false_type{});
-        else epilogue(std::false_type{}, std::false_type{});
+        // SWAP orientation: acc[i][j] holds C^T of the 32x32 tile: lane column r <-> row m of C, register e <-> column
+        // n = 8*(e>>2) + 4*h + (e&3): four consecutive columns per register quad -> float4 everywhere (N % 4 == 0, 16-byte aligned rows)
+        auto epilogue_sw = [&](auto ADD, auto FULL) {
+            constexpr bool has_add = decltype(ADD)::value, full = decltype(FULL)::value;
+            const int act = p.relu;
+            const int nb = en0 + wn * (WNT * 32) + 4 * h;
+            p_static_for<WMT>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const int m = em0 + wm * (WMT * 32) + i * 32 + r;
+                const long mc = min(m, p.M - 1);
+                p_static_for<WNT>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    // phase 1: the four 16-byte operands of this 32x32 tile's row go in flight together
+                    float4 bias4[4], addv[4], mskv[4], oldv[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nc = min(nb + j * 32 + 8 * g, p.N - 4);
+                        bias4[g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (has_add) addv[g] = *reinterpret_cast<const float4*>(p.add_src + mc * p.ld_add + nc);
+                        if (full) {
+                            mskv[g] = p.mask_src ? *reinterpret_cast<const float4*>(p.mask_src + mc * p.ld_mask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
+                            oldv[g] = p.accumulate ? *reinterpret_cast<const float4*>(p.C + mc * p.ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                    p_static_for<4>([&](auto Gq) {
+                        constexpr int g = decltype(Gq)::value;
+                        const int n = nb + j * 32 + 8 * g;
+                        float v[4];
+                        const float bb[4] = {bias4[g].x, bias4[g].y, bias4[g].z, bias4[g].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = alpha * acc[i][j][4 * g + c] + bb[c];
+                        if (has_add) { v[0] += addv[g].x; v[1] += addv[g].y; v[2] += addv[g].z; v[3] += addv[g].w; }
+                        if (act == 1) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                        } else if (act == 2) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = v[c] / (1.0f + __expf(-1.702f * v[c]));
+                        }
+                        if constexpr (full) {
+                            if (p.mask_src) {
+                                const float mk[4] = {mskv[g].x, mskv[g].y, mskv[g].z, mskv[g].w};
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) v[c] = (mk[c] > 0.f) ? v[c] * p.mask_scale : 0.f;
+                            }
+                            if (p.drop_p > 0.f) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    v[c] *= qt_drop_mult(p.drop_seed, (unsigned long long)m * (unsigned long long)p.N + (n + c), p.drop_p, p.inv_keep);
+                            }
+                            v[0] += oldv[g].x; v[1] += oldv[g].y; v[2] += oldv[g].z; v[3] += oldv[g].w;
+                        }
+                        if (m < p.M && n < p.N) *reinterpret_cast<float4*>(p.C + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    });
+                });
+            });
+        };
+        if constexpr (SWAP) {
+            if (p.mask_src || p.drop_p > 0.f || p.accumulate) {
+                if (p.add_src) epilogue_sw(std::true_type{}, std::true_type{}); else epilogue_sw(std::false_type{}, std::true_type{});
+            } else if (p.add_src) epilogue_sw(std::true_type{}, std::false_type{});
+            else epilogue_sw(std::false_type{}, std::false_type{});
+        } else {
+            if (p.mask_src || p.drop_p > 0.f || p.accumulate) {
+                if (p.add_src) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{});
+            } else if (p.add_src) epilogue(std::true_type{}, std::false_type{});
+            else epilogue(std::false_type{}, std::false_type{});
+        }
         if (!more) break;
     }
 }
@@ -632,19 +726,22 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
     const long total_work = tiles * split_k;
     dim3 grid((unsigned)(total_work > slots ? slots : total_work));
     const size_t lds = P_LDS_BYTES;
-#define QT_PS(AK_, BK_)                                                                                       \
-    do {                                                                                                      \
-        auto kern = qt_gemm_ps_kernel<AK_, BK_>;                                                              \
-        if (!ps_attr_done) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);                                                \
-    } while (0)
-    if (!ps_attr_done) {      // all four instances once (load-time cost, not per launch)
-        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the 16-byte epilogue needs 16-byte aligned rows of C and of every epilogue operand; anything else keeps the dword orientation
+    const bool vec_ok = N % 4 == 0 && ldc % 4 == 0 && qt_aligned16(C) && (!bias || qt_aligned16(bias)) &&
+                        (!add_src || (qt_aligned16(add_src) && ld_add % 4 == 0)) && (!mask_src || (qt_aligned16(mask_src) && ld_mask % 4 == 0));
+    const bool swap = split_k == 1 && vec_ok;
+    if (!ps_attr_done) {      // every instance once (load-time cost, not per launch)
+#define QT_PS_ATTR(AK_, BK_, SW_) (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<AK_, BK_, SW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        QT_PS_ATTR(false, false, false); QT_PS_ATTR(false, true, false); QT_PS_ATTR(true, false, false); QT_PS_ATTR(true, true, false);
+        QT_PS_ATTR(false, false, true); QT_PS_ATTR(false, true, true); QT_PS_ATTR(true, false, true); QT_PS_ATTR(true, true, true);
+#undef QT_PS_ATTR
         ps_attr_done = true;
     }
+#define QT_PS(AK_, BK_)                                                                                       \
+    do {                                                                                                      \
+        if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, true>), grid, dim3(512), lds, st, a);        \
+        else hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, false>), grid, dim3(512), lds, st, a);            \
+    } while (0)
     if (!a_kslow && !b_kslow) QT_PS(false, false);
     else if (!a_kslow && b_kslow) QT_PS(false, true);
     else if (a_kslow && !b_kslow) QT_PS(true, false);
