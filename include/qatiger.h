@@ -175,6 +175,21 @@ int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, floa
                const float* mask_src, long ld_mask, float mask_scale,
                float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
 
+/* ---- BASELINE configs[4] ("fp8 MFMA on projection GEMMs"): e4m3 operand images and the GEMM on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 accumulate, fp32 epilogue).  Outside the 1e-3 parity gate by construction: judged by
+ * arg-max / top-k agreement with the fp32 path. ---- */
+
+/* fp32 [R, C] -> e4m3 (OCP) image, one byte per element, R rows of ld_img_bytes (multiple of 128, >= C; C multiple of 128):
+ * x * 2^e with 2^e * (*amax) in [128, 256) (amax nullable: unscaled). */
+int qt_quant_fp8(void* stream, const float* x, long ldx, long R, int C, const float* amax, void* img, long ld_img_bytes);
+/* C[M,N] = epilogue(alpha / (s_a s_b) * A B^T), A image [M rows][K], B image [N rows][K] (nn.Linear weight layout), K % 128 == 0;
+ * epilogue of qt_gemm_f32; returns -4 without touching C when the shape does not fit the 256x256 tile. */
+int qt_gemm_f8(void* stream, int M, int N, int K, float alpha,
+               const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+               float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+               const float* mask_src, long ld_mask, float mask_scale,
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
+
 /* ---- frozen CLIP text tower (forward only) and evaluation counters ---- */
 
 /* Causal self-attention core of the text transformer: softmax(q k^T * scale + mask) v with the additive

@@ -76,6 +76,15 @@ __host__ __device__ inline float qt_plane_scale(float amax) {
     return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
 }
 
+// e4m3 images: 2^e * amax lands in [2^7, 2^8) (the format's largest finite value is 448)
+__host__ __device__ inline float qt_fp8_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int e = 7 - ex;
+    e = e > 126 ? 126 : (e < -126 ? -126 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+
 // one LDS-DMA wave instruction: 64 lanes x 16 B from (sbase + voff[lane]) to LDS bytes [lds_addr, lds_addr + 1024).
 // lds_addr and sbase are wave-uniform (SGPRs).  M0 carries the LDS address; nothing else in this kernel uses M0.
 __device__ __forceinline__ void qt_dma16(unsigned lds_addr, const void* sbase, unsigned voff) {
@@ -92,8 +101,14 @@ template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_
 // SWAP: the MFMAs take (B fragment, A fragment), i.e. each 32x32 accumulator holds C^T: a lane then owns FOUR CONSECUTIVE COLUMNS
 // of one row of C per register quad, and the write-out (and every epilogue operand) moves as 16-byte vectors — 32 stores per lane
 // instead of 128.  Split-K launches keep the plain orientation: their fp32 atomics run at full rate only on 128-byte row segments.
-template <bool AKS, bool BKS, bool SWAP>
+// FMT 0: fp16 (hi | lo) lines, 32 k per 128-byte line, three v_mfma_f32_32x32x16_f16 per product (fp32-equivalent).
+// FMT 1: e4m3 fp8 lines, 128 k per 128-byte line, ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 64 k (unit block scales): BASELINE
+//        configs[4] ("fp8 MFMA on projection GEMMs"); row-form operands only (forward GEMMs).  Same tile, same LDS map, same DMA
+//        schedule: a K step is always one 128-byte line per row.
+template <bool AKS, bool BKS, bool SWAP, int FMT>
 __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
+    static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
+    constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
     constexpr int WMT = 4, WNT = 2, NWN = 4;          // wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32
     constexpr int BM = 256, BN = 256, GM = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,21 +166,21 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         }
     };
     auto dma_a = [&](int k0, int stage) {
-        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 >> 5) * 128;
+        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 / KS) * 128;
         const unsigned la = lds0 + stage * P_OPER + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
     auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
-        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 >> 5) * 128;
+        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 / KS) * 128;
         qt_dma16(lds0 + stage * P_OPER + wave * 4096 + i * 1024, sa, offA[i]);
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
-        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
+        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
         qt_dma16(lds0 + P_B_BASE + stage * P_OPER + wave * 4096 + i * 1024, sb, offB[i]);
     };
     auto dma_b = [&](int k0, int stage) {
-        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 >> 5) * 128;
+        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
         const unsigned lb = lds0 + P_B_BASE + stage * P_OPER + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) qt_dma16(lb + i * 1024, sb, offB[i]);
@@ -184,6 +199,19 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 8) * 64 + ((c ^ q) * 64));   // c = unit & 3
             if (!BKS) fb[c] = (unsigned)((wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
             else      fb[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
+        }
+    }
+
+    // fp8 lines: MFMA q (k 64q .. 64q+63) takes bytes [64q + 32h, +32) of a row from every lane: slots 4q + 2h and 4q + 2h + 1.
+    // (Both operands use the same lane -> k assignment, so the product is the dot product whatever the instruction's internal k order.)
+    unsigned fa8[4], fb8[4];
+    {
+        const int x = (r >> 1) & 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                     // c = q*2 + half
+            const int slot = 4 * (c >> 1) + 2 * h + (c & 1);
+            fa8[c] = (unsigned)((wm * 128 + r) * 128 + ((slot ^ x) * 16));
+            fb8[c] = (unsigned)((wn * 64 + r) * 128 + ((slot ^ x) * 16));
         }
     }
 
@@ -249,21 +277,60 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         });
     };
 
+    // fp8: 8 segments (64-k half q, A row tile i): [32-byte fragments of the next segment] -> [one DMA piece] -> [2 MFMAs]
+    auto compute8 = [&](unsigned sbase, unsigned sbase_b, auto&& issue) {
+        typedef int intx8 __attribute__((ext_vector_type(8)));
+        uint4 a0[2], a1[2], b0[2][WNT], b1[2][WNT];
+        auto load_a = [&](int q, int i, uint4& x0, uint4& x1) {
+            x0 = lds_u4(sbase + fa8[2 * q + 0] + i * 4096);
+            x1 = lds_u4(sbase + fa8[2 * q + 1] + i * 4096);
+        };
+        auto load_b = [&](int q, uint4* x0, uint4* x1) {
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                x0[j] = lds_u4(sbase_b + fb8[2 * q + 0] + j * 4096);
+                x1[j] = lds_u4(sbase_b + fb8[2 * q + 1] + j * 4096);
+            }
+        };
+        auto pack = [](const uint4& lo, const uint4& hi) {
+            intx8 v; v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w; v[4] = (int)hi.x; v[5] = (int)hi.y; v[6] = (int)hi.z; v[7] = (int)hi.w;
+            return v;
+        };
+        load_b(0, b0[0], b1[0]);
+        load_a(0, 0, a0[0], a1[0]);
+        p_static_for<8>([&](auto SEG) {
+            constexpr int seg = decltype(SEG)::value, q = seg >> 2, i = seg & 3, cur = seg & 1;
+            if constexpr (seg + 1 < 8) {
+                constexpr int q1 = (seg + 1) >> 2, i1 = (seg + 1) & 3;
+                if constexpr (i1 == 0) load_b(q1, b0[q1], b1[q1]);
+                load_a(q1, i1, a0[cur ^ 1], a1[cur ^ 1]);
+            }
+            issue(SEG);
+            p_static_for<WNT>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const intx8 va = pack(a0[cur], a1[cur]), vb = pack(b0[q][j], b1[q][j]);
+                // cbsz / blgp 0 = e4m3 for A / B; block scales 2^0 (E8M0 127): the per-tensor scale is applied in the epilogue
+                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vb, va, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                else      acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            });
+        });
+    };
+
     long w = slot;
     if (w >= total) return;
     decode(w);
     set_offsets();
     if (p.debug & 8) {                                 // probe: de-synchronise the CUs' tile phases (write-out bursts, DMA bursts)
-        const int d = (int)((blockIdx.x >> 3) & 7) * ((kend - kbeg) / PBK);
+        const int d = (int)((blockIdx.x >> 3) & 7) * ((kend - kbeg) / KS);
         for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(6);       // ~384 cycles x K steps x (0..7) = 0..7/8 of a tile
     }
     // Stages are addressed by running step counters that continue across tiles: A step g lives in stage g % 3, B step g in g & 1.
     int sa_cur = 0, gb = 0;                            // A stage of the current step; B step parity
     auto nxt3 = [](int s) { return s == P_A_STAGES - 1 ? 0 : s + 1; };
     {   // first tile: A(0), A(1), B(0)
-        const int nk0 = (kend - kbeg) / PBK;
+        const int nk0 = (kend - kbeg) / KS;
         dma_a(kbeg, sa_cur);
-        if (nk0 > 1) dma_a(kbeg + PBK, nxt3(sa_cur));
+        if (nk0 > 1) dma_a(kbeg + KS, nxt3(sa_cur));
         dma_b(kbeg, gb & 1);
     }
     for (;;) {
@@ -273,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             for (int j = 0; j < WNT; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        const int nk = (kend - kbeg) / PBK;
+        const int nk = (kend - kbeg) / KS;
         for (int t = 0; t < nk; ++t) {
             // Issue order is B(t+1) then A(t+2) at every step, so when step t opens the only younger transfers than the ones it
             // reads (A(t): two steps old, B(t): one step old) are the 4 pieces of A(t+1) — if that was issued at all.  The first
@@ -284,14 +351,17 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
             const bool do_b = (t + 1 < nk) && !(p.debug & 2), do_a = (t + 2 < nk) && !(p.debug & 2);
-            const int kb1 = kbeg + (t + 1) * PBK, ka2 = kbeg + (t + 2) * PBK;
+            const int kb1 = kbeg + (t + 1) * KS, ka2 = kbeg + (t + 2) * KS;
             const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
             auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), pieces 4-7: A(t+2) — this order is what vmcnt(4) counts on
                 constexpr int seg = decltype(SEG)::value;
                 if constexpr (seg < 4) { if (do_b) dma_b1(kb1, stb, seg); }
                 else { if (do_a) dma_a1(ka2, sta, seg - 4); }
             };
-            if (!(p.debug & 4)) compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
+            if (!(p.debug & 4)) {
+                if constexpr (FMT == 1) compute8((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
+                else compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
+            }
             else p_static_for<8>([&](auto SEG) { issue(SEG); });
             sa_cur = nxt3(sa_cur);
             ++gb;
@@ -306,16 +376,16 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             set_offsets();
             // next tile's A(0), A(1), B(0): their stages were last read at steps g-2, g-1, g-1 of the running count, and every wave
             // has passed the barrier of step g (the last one of this tile), i.e. has finished multiplying step g-1
-            const int nk1 = (kend - kbeg) / PBK;
+            const int nk1 = (kend - kbeg) / KS;
             dma_a(kbeg, sa_cur);
-            if (nk1 > 1) dma_a(kbeg + PBK, nxt3(sa_cur));
+            if (nk1 > 1) dma_a(kbeg + KS, nxt3(sa_cur));
             dma_b(kbeg, gb & 1);
         }
         if ((p.debug & 1) && acc[0][0][0] != 12345.678f) { if (!more) break; continue; }
         // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
         float alpha = p.alpha;
-        if (p.a_amax) alpha /= qt_plane_scale(*p.a_amax);
-        if (p.b_amax) alpha /= qt_plane_scale(*p.b_amax);
+        if (p.a_amax) alpha /= (FMT == 1 ? qt_fp8_scale(*p.a_amax) : qt_plane_scale(*p.a_amax));
+        if (p.b_amax) alpha /= (FMT == 1 ? qt_fp8_scale(*p.b_amax) : qt_plane_scale(*p.b_amax));
         const int mrow0 = em0 + wm * (WMT * 32) + 4 * h;
         const int ncol0 = en0 + wn * (WNT * 32) + r;
         float bias_v[WNT];
@@ -667,25 +737,24 @@ extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int 
 
 static bool ps_attr_done = false;
 
-// C[M,N] = epilogue(alpha/(s_a s_b) * op(A) op(B)) on split images.
-//   a_kslow = 0: A image is [M rows][K]  (K contiguous)      a_kslow = 1: A image is [K rows][M]
-//   b_kslow = 0: B image is [N rows][K]  (Linear weight)     b_kslow = 1: B image is [K rows][N]
-// Returns QT_ERR_UNSUPPORTED (without touching C) when the shape does not fit (callers then use qt_gemm_x3).
-extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
-                          const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
-                          float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
-                          const float* mask_src, long ld_mask, float mask_scale,
-                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
-    QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_ps: bad problem");
-    QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_ps: drop_p=%f", drop_p);
-    QT_CHECK_ARG(ldc >= N && lda_bytes % 128 == 0 && ldb_bytes % 128 == 0 && qt_aligned16(A) && qt_aligned16(B), "qt_gemm_ps: image pitch / alignment");
-    if (K % PBK != 0) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: K=%d is not a multiple of 32", K);
-    if ((a_kslow && M % 32) || (b_kslow && N % 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: a K-slow operand needs its width to be a multiple of 32");
-    if (M < 256 || N < 128) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: problem too small for the 256x256 tile");
+// Shared launcher.  fmt 0: fp16 (hi | lo) lines, K step 32;  fmt 1: e4m3 lines, K step 128, row-form operands only.
+static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                      const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                      float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+                      const float* mask_src, long ld_mask, float mask_scale,
+                      float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+    const int KS = fmt == 1 ? 128 : PBK;
+    QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "%s: bad problem", who);
+    QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "%s: drop_p=%f", who, drop_p);
+    QT_CHECK_ARG(ldc >= N && lda_bytes % 128 == 0 && ldb_bytes % 128 == 0 && qt_aligned16(A) && qt_aligned16(B), "%s: image pitch / alignment", who);
+    QT_CHECK_ARG(fmt == 0 || (!a_kslow && !b_kslow), "%s: fp8 lines are K-contiguous only", who);
+    if (K % KS != 0) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: K=%d is not a multiple of %d", who, K, KS);
+    if ((a_kslow && M % 32) || (b_kslow && N % 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: a K-slow operand needs its width to be a multiple of 32", who);
+    if (M < 256 || N < 128) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: problem too small for the 256x256 tile", who);
     {   // per-lane source offsets are 32-bit byte offsets from a wave-uniform base
         const long spanA = a_kslow ? 32 * lda_bytes + 4L * M : (long)M * lda_bytes;
         const long spanB = b_kslow ? 32 * ldb_bytes + 4L * N : (long)N * ldb_bytes;
-        if (spanA >= (1L << 32) || spanB >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_ps: operand spans more than 4 GiB");
+        if (spanA >= (1L << 32) || spanB >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: operand spans more than 4 GiB", who);
     }
     hipStream_t st = (hipStream_t)stream;
     PlaneArgs a;
@@ -695,33 +764,33 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QT_PS_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
-    QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_ps: split_k>1 needs a linear epilogue");
+    QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "%s: split_k>1 needs a linear epilogue", who);
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const long tiles = (long)tiles_m * tiles_n;
     const long slots = 256;
     a.tiles_m = tiles_m; a.tiles_n = tiles_n;
     if (split_k <= 0) {
         split_k = 1;
-        if (plain_epilogue && tiles < 2 * slots && K >= 16 * PBK) {      // same cost model as qt_gemm_x3
+        if (plain_epilogue && tiles < 2 * slots && K >= 16 * KS) {      // same cost model as qt_gemm_x3
             const long ovh = 16;
-            long maxs = K / (4 * PBK);
+            long maxs = K / (4 * KS);
             if (maxs > 64) maxs = 64;
             long best = -1;
             for (long s = 1; s <= maxs; ++s) {
                 const long rounds = (tiles * s + slots - 1) / slots;
-                const long ksteps = ((K + s - 1) / s + PBK - 1) / PBK;
+                const long ksteps = ((K + s - 1) / s + KS - 1) / KS;
                 const long cost = rounds * (ksteps + ovh);
                 if (best < 0 || cost < best) { best = cost; split_k = (int)s; }
             }
         }
     }
     int kps = (K + split_k - 1) / split_k;
-    kps = ((kps + PBK - 1) / PBK) * PBK;
+    kps = ((kps + KS - 1) / KS) * KS;
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
     if (split_k > 1 && !accumulate) {
         hipError_t e = qt_zero_2d(C, ldc, M, N, st);
-        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_ps: zeroing C: %s", hipGetErrorString(e));
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "%s: zeroing C: %s", who, hipGetErrorString(e));
     }
     const long total_work = tiles * split_k;
     dim3 grid((unsigned)(total_work > slots ? slots : total_work));
@@ -731,22 +800,87 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
                         (!add_src || (qt_aligned16(add_src) && ld_add % 4 == 0)) && (!mask_src || (qt_aligned16(mask_src) && ld_mask % 4 == 0));
     const bool swap = split_k == 1 && vec_ok;
     if (!ps_attr_done) {      // every instance once (load-time cost, not per launch)
-#define QT_PS_ATTR(AK_, BK_, SW_) (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<AK_, BK_, SW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-        QT_PS_ATTR(false, false, false); QT_PS_ATTR(false, true, false); QT_PS_ATTR(true, false, false); QT_PS_ATTR(true, true, false);
-        QT_PS_ATTR(false, false, true); QT_PS_ATTR(false, true, true); QT_PS_ATTR(true, false, true); QT_PS_ATTR(true, true, true);
+#define QT_PS_ATTR(AK_, BK_, SW_, F_) (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<AK_, BK_, SW_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        QT_PS_ATTR(false, false, false, 0); QT_PS_ATTR(false, true, false, 0); QT_PS_ATTR(true, false, false, 0); QT_PS_ATTR(true, true, false, 0);
+        QT_PS_ATTR(false, false, true, 0); QT_PS_ATTR(false, true, true, 0); QT_PS_ATTR(true, false, true, 0); QT_PS_ATTR(true, true, true, 0);
+        QT_PS_ATTR(false, false, false, 1); QT_PS_ATTR(false, false, true, 1);
 #undef QT_PS_ATTR
         ps_attr_done = true;
     }
 #define QT_PS(AK_, BK_)                                                                                       \
     do {                                                                                                      \
-        if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, true>), grid, dim3(512), lds, st, a);        \
-        else hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, false>), grid, dim3(512), lds, st, a);            \
+        if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, true, 0>), grid, dim3(512), lds, st, a);     \
+        else hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, false, 0>), grid, dim3(512), lds, st, a);         \
     } while (0)
-    if (!a_kslow && !b_kslow) QT_PS(false, false);
+    if (fmt == 1) {
+        if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<false, false, true, 1>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((qt_gemm_ps_kernel<false, false, false, 1>), grid, dim3(512), lds, st, a);
+    } else if (!a_kslow && !b_kslow) QT_PS(false, false);
     else if (!a_kslow && b_kslow) QT_PS(false, true);
     else if (a_kslow && !b_kslow) QT_PS(true, false);
     else QT_PS(true, true);
 #undef QT_PS
-    QT_CHECK_LAUNCH("qt_gemm_ps");
+    QT_CHECK_LAUNCH(who);
+    return QT_OK;
+}
+
+// C[M,N] = epilogue(alpha/(s_a s_b) * op(A) op(B)) on split images.
+//   a_kslow = 0: A image is [M rows][K]  (K contiguous)      a_kslow = 1: A image is [K rows][M]
+//   b_kslow = 0: B image is [N rows][K]  (Linear weight)     b_kslow = 1: B image is [K rows][N]
+// Returns QT_ERR_UNSUPPORTED (without touching C) when the shape does not fit (callers then use qt_gemm_x3).
+extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                          const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                          float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+                          const float* mask_src, long ld_mask, float mask_scale,
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+    return plane_gemm("qt_gemm_ps", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
+                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k);
+}
+
+// BASELINE configs[4]: C[M,N] = epilogue(alpha/(s_a s_b) * A B^T) with A [M rows][K] and B [N rows][K] (nn.Linear weight) given as
+// e4m3 images (qt_quant_fp8: one byte per element, row pitch in bytes a multiple of 128), on v_mfma_scale_f32_32x32x64_f8f6f4
+// with fp32 accumulation and the fp32 epilogue of qt_gemm_f32.  K must be a multiple of 128.
+extern "C" int qt_gemm_f8(void* stream, int M, int N, int K, float alpha,
+                          const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                          float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+                          const float* mask_src, long ld_mask, float mask_scale,
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+    return plane_gemm("qt_gemm_f8", 1, stream, 0, 0, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
+                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k);
+}
+
+// fp32 [R, C] -> e4m3 image [R][C bytes] (row pitch ld_img bytes), x * 2^e with 2^e * amax in [128, 256); C a multiple of 16.
+__global__ __launch_bounds__(256) void qt_quant_fp8_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
+                                                           char* __restrict__ img, long ld_img) {
+    const float s = amax ? qt_fp8_scale(*amax) : 1.0f;
+    const int g16 = C >> 4;
+    const long total = R * g16;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / g16; const int c16 = (int)(idx - row * g16);
+        const float* src = x + row * ldx + c16 * 16;
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + 4 * u);
+        uint4 o;
+        unsigned* ow = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[u].x * s, v[u].y * s, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[u].z * s, v[u].w * s, pk, true);
+            ow[u] = (unsigned)pk;
+        }
+        *reinterpret_cast<uint4*>(img + row * ld_img + c16 * 16) = o;
+    }
+}
+
+extern "C" int qt_quant_fp8(void* stream, const float* x, long ldx, long R, int C, const float* amax, void* img, long ld_img_bytes) {
+    QT_CHECK_ARG(x && img && R > 0 && C > 0 && ldx >= C, "qt_quant_fp8: bad arguments");
+    QT_CHECK_ARG(C % 128 == 0, "qt_quant_fp8: the image is made of 128-byte lines (C=%d)", C);
+    QT_CHECK_ARG(ldx % 4 == 0 && qt_aligned16(x) && qt_aligned16(img) && ld_img_bytes % 128 == 0 && ld_img_bytes >= C,
+                 "qt_quant_fp8: alignment (ldx=%ld, ld_img=%ld)", ldx, ld_img_bytes);
+    long blocks = (R * (C >> 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(qt_quant_fp8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, amax, (char*)img, ld_img_bytes);
+    QT_CHECK_LAUNCH("qt_quant_fp8");
     return QT_OK;
 }

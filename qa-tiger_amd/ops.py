@@ -162,6 +162,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3."""
     a, b = as2d(a), as2d(b)
     _dev(a, b, bias, add, mask_src, out)
+    if mode == 'fp8':                                   # configs[4]: only the Linear projections run on fp8 images (LinearFn);
+        mode = 'f16x3'                                  # head-batched and odd-shaped products stay fp32-equivalent
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     N, Kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     if K != Kb:
@@ -281,6 +283,43 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
     return out
 
 
+def quant_fp8(x: Tensor, amax: Optional[Tensor] = None) -> SplitImage:
+    """fp32 [rows, cols] -> e4m3 image (one byte per element, per-tensor power-of-two scale from max|x|): BASELINE configs[4]."""
+    x = as2d(x)
+    _dev(x)
+    R, Cc = x.shape
+    if Cc % 128:
+        raise _lib.QTError(f'quant_fp8: {Cc} columns is not a multiple of 128')
+    if amax is None:
+        amax = amax_of(x)
+    img = torch.empty((R, Cc), device=x.device, dtype=torch.uint8)
+    _lib.check(_lib.load().qt_quant_fp8(_stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), Cc), 'qt_quant_fp8')
+    return SplitImage(img, R, Cc, amax)
+
+
+def gemm_f8(a: SplitImage, b: SplitImage, *, out: Optional[Tensor] = None, bias: Optional[Tensor] = None, add: Optional[Tensor] = None,
+            relu: int = 0, drop_p: float = 0.0, seed: int = 0, alpha: float = 1.0) -> Optional[Tensor]:
+    """out[M,N] = epilogue(alpha * a @ b^T) on e4m3 images (fp8 MFMA, fp32 accumulate); None when the shape does not fit."""
+    M, K, N = a.rows, a.cols, b.rows
+    if K != b.cols:
+        raise _lib.QTError(f'gemm_f8: inner dimensions differ ({K} vs {b.cols})')
+    _dev(bias, add, out)
+    if out is None:
+        out = torch.empty((M, N), device=a.data.device, dtype=torch.float32)
+    if add is not None:
+        add = as2d(add)
+    rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, 0, 0, 'fp8'), lambda: _lib.load().qt_gemm_f8(
+        _stream(), M, N, K, float(alpha), _ptr(a.data), a.cols, _ptr(a.amax), _ptr(b.data), b.cols, _ptr(b.amax),
+        _ptr(out), _ld(out), _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
+        None, 0, 1.0, float(drop_p), C.c_ulonglong(seed), 0, 1))
+    if rc == -4:
+        if timer is not None:
+            timer.records.pop()
+        return None
+    _lib.check(rc, 'qt_gemm_f8')
+    return out
+
+
 def colsum(x: Tensor) -> Tensor:
     x = as2d(x)
     _dev(x)
@@ -370,6 +409,36 @@ def weight_image(weight: Tensor) -> Optional[SplitImage]:
     return SplitImage(img.data[r0:r0 + weight.shape[0]], weight.shape[0], cols, img.amax)
 
 
+def weight_image_fp8(weight: Tensor) -> Optional[SplitImage]:
+    """e4m3 image of a Linear weight (or of a row slice of one), cached on the parameter like `weight_image`."""
+    base = weight._base if weight._base is not None else weight
+    if base.dim() != 2 or weight.dim() != 2 or not base.is_contiguous() or weight.stride() != base.stride():
+        return None
+    rows_b, cols = base.shape
+    if cols % 128 or weight.shape[1] != cols:
+        return None
+    key = (base._version, weights_epoch, base.data_ptr())
+    cached = getattr(base, '_qt_wimg8', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = (key, quant_fp8(base.detach()))
+        base._qt_wimg8 = cached
+    img = cached[1]
+    r0 = (weight.storage_offset() - base.storage_offset()) // cols
+    if weight.shape[0] == rows_b and r0 == 0:
+        return img
+    return SplitImage(img.data[r0:r0 + weight.shape[0]], weight.shape[0], cols, img.amax)
+
+
+def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
+    cached = getattr(x, '_qt_img8', None)
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
+        return cached[1]
+    img = quant_fp8(x2.detach())
+    x._qt_img8 = ((x._version, x.data_ptr()), img)
+    return img
+
+
 def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     """Split image of an activation (x2 = the [rows, k_in] view of x), made once per tensor object: the layers that read the
     same tensor (the three in-projections of AVQCrossAttn, ...) and the dW GEMM of the backward share it."""
@@ -391,6 +460,18 @@ class LinearFn(torch.autograd.Function):
         x2 = as2d(x)
         y = None
         ximg = wimg = None
+        if precision['fwd'] == 'fp8':
+            # BASELINE configs[4]: projection GEMMs on fp8 MFMA (forward only; the router / Gaussian / softmax / LayerNorm
+            # statistics and every small GEMM stay in fp32 — SURVEY.md Appendix E)
+            if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+                raise _lib.QTError("precision 'fp8' (BASELINE configs[4]) is a forward-only mode: run it under torch.no_grad()")
+            if x2.shape[0] >= 256 and weight.shape[0] >= 128 and weight.shape[1] % 128 == 0:
+                wq = weight_image_fp8(weight)
+                if wq is not None:
+                    y = gemm_f8(input_image_fp8(x, x2), wq, bias=bias, add=residual, relu=int(relu), drop_p=drop_p, seed=seed)
+            if y is None:
+                y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode='f16x3')
+            return y.reshape(*shape[:-1], weight.shape[0])
         if _plane_ok(x2.shape[0], weight.shape[0], weight.shape[1]):
             wimg = weight_image(weight)
             if wimg is not None:

@@ -119,3 +119,48 @@ def test_gemm_ps_scaled_operands_any_magnitude(ops, sa, sb):
 def test_gemm_ps_refuses_what_it_cannot_tile(ops):
     a, b = rnd(128, 64, seed=13), rnd(128, 64, seed=14)
     assert ops.gemm_ps(ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV))) is None      # M < 256: the caller falls back
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE configs[4]: e4m3 images + the GEMM on v_mfma_scale_f32_32x32x64_f8f6f4
+# --------------------------------------------------------------------------- #
+def _e4m3(x):
+    """Round to OCP e4m3fn on the CPU (torch's float8_e4m3fn is that format)."""
+    return x.to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 128, 128), (512, 256, 768), (300, 384, 1024), (1024, 256, 2304)])
+def test_gemm_f8_is_exact_on_fp8_representable_operands(ops, M, N, K):
+    """Small-integer operands are exact in e4m3 and their products/sums exact in fp32: the kernel must reproduce the integer
+    result bit for bit — this pins the lane <-> (row, k) assignment of the fp8 MFMA fragments."""
+    g = torch.Generator().manual_seed(31)
+    a = torch.randint(-4, 5, (M, K), generator=g).float()
+    b = torch.randint(-3, 4, (N, K), generator=g).float()
+    b[:, 0] = torch.arange(N).float() % 5 - 2                    # asymmetric structure
+    ia, ib = ops.quant_fp8(a.to(DEV)), ops.quant_fp8(b.to(DEV))
+    out = ops.gemm_f8(ia, ib)
+    assert out is not None
+    assert torch.equal(out.cpu(), (a.double() @ b.double().t()).float())
+
+
+def test_quant_fp8_matches_torch_e4m3(ops):
+    x = rnd(64, 256, seed=41, scale=3.0)
+    img = ops.quant_fp8(x.to(DEV))
+    s = 2.0 ** (7 - int(np.floor(np.log2(float(x.abs().max())))))
+    got = img.data.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.equal(got, _e4m3(x * s))
+    assert 128 <= float(got.abs().max()) <= 256
+
+
+def test_gemm_f8_random_operands_and_epilogue(ops):
+    M, N, K = 512, 256, 768
+    a, b = rnd(M, K, seed=42, scale=0.7), rnd(N, K, seed=43, scale=0.05)
+    bias, res = rnd(N, seed=44), rnd(M, N, seed=45)
+    ia, ib = ops.quant_fp8(a.to(DEV)), ops.quant_fp8(b.to(DEV))
+    out = ops.gemm_f8(ia, ib, bias=bias.to(DEV), add=res.to(DEV), relu=1)
+    # exact reference of the mode's definition: operands rounded to e4m3 after the power-of-two scale, fp32+ accumulation
+    sa = 2.0 ** (7 - int(np.floor(np.log2(float(a.abs().max()))))); sb = 2.0 ** (7 - int(np.floor(np.log2(float(b.abs().max())))))
+    ref = torch.relu((_e4m3(a * sa).double() @ _e4m3(b * sb).double().t()) / (sa * sb) + bias.double() + res.double())
+    assert rel(out, ref) < 2e-6
+    full = torch.relu(a.double() @ b.double().t() + bias.double() + res.double())
+    assert 1e-3 < rel(out, full) < 0.2                     # really 3-bit-significand operands, and not garbage

@@ -335,6 +335,57 @@ def test_reduced_precision_mode_argmax_agreement(qt, synth):
     assert agree >= 0.75
 
 
+def _topk_order_agreement(model, ref_inds):
+    """fraction of samples whose top-k expert ORDER equals the reference's, per aggregator"""
+    return {a: float((getattr(model, a).last['topk_inds'].cpu() == ref_inds[a]).all(dim=1).float().mean())
+            for a in ('at_aggregator', 'vt_aggregator')}
+
+
+def test_config5_fp8_projection_gemms_agreement(qt, synth, oracle):
+    """BASELINE configs[4]: projection GEMMs on fp8 MFMA (e4m3 images, fp32 accumulate; router / Gaussian / softmax / LayerNorm
+    statistics in fp32), forward.  Outside the 1e-3 gate by construction; what config 5 asks for is agreement with the fp32 path:
+    arg-max agreement RATE and top-k ORDER agreement, here against (a) the reference's own config2_b8
+    golden and (b) the CPU oracle at the config's B = 512."""
+    keep = dict(qt.ops.precision)
+    report = {}
+    try:
+        # (a) reference golden, B = 8
+        g = load_golden('config2_b8')
+        cfg, seed = golden_cfg(synth, 'config2_b8')
+        model = build(qt, synth, cfg, seed)
+        inp = to_dev(synth.make_inputs(cfg, seed))
+        qt.ops.precision.update(fwd='fp8', bwd='fp8')
+        with torch.no_grad():
+            out = model(inp)['out'].cpu().numpy()
+        report['b8'] = dict(argmax=float((out.argmax(-1) == g['logits'].argmax(-1)).mean()), rel_logit_err=rel_err(out, g['logits']),
+                            topk_order=_topk_order_agreement(model, {a: torch.from_numpy(g[f'tap/{a}.topk_inds']) for a in ('at_aggregator', 'vt_aggregator')}))
+        assert np.isfinite(out).all() and 1e-4 < report['b8']['rel_logit_err'] < 0.5      # really fp8, and not garbage
+        with pytest.raises(qt.QTError, match='forward-only'):
+            model(inp)                                                                    # autograd on: refused loudly
+        # (b) oracle at B = 512
+        qt.ops.precision.update(keep)
+        cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 512})
+        P = synth.make_state_dict(cfg, 713)
+        inp = synth.make_inputs(cfg, 713)
+        model = qt.QA_TIGER(**cfg.model_kwargs())
+        model.load_state_dict(P, strict=True)
+        model = model.to(DEV).eval()
+        taps = {}
+        with torch.no_grad():
+            ref = oracle.qa_tiger_forward(P, inp, cfg.K, cfg.k, taps=taps).numpy()
+        qt.ops.precision.update(fwd='fp8', bwd='fp8')
+        with torch.no_grad():
+            out = model(to_dev(inp))['out'].cpu().numpy()
+        report['b512'] = dict(argmax=float((out.argmax(-1) == ref.argmax(-1)).mean()), rel_logit_err=rel_err(out, ref),
+                              topk_order=_topk_order_agreement(model, {a: taps[f'{a}.topk_inds'] for a in ('at_aggregator', 'vt_aggregator')}))
+    finally:
+        qt.ops.precision.update(keep)
+    print('config5 (fp8 projection GEMMs) agreement with the fp32 path:', report)
+    assert np.isfinite(out).all()
+    assert report['b512']['argmax'] >= 0.5 and report['b8']['argmax'] >= 0.5
+    assert report['b512']['rel_logit_err'] < 0.5
+
+
 @pytest.mark.parametrize('shape', [(300, 512, 256, False, True), (512, 300, 1000, True, False), (256, 256, 4096, False, False)])
 def test_bf16x1_gemm(qt, shape):
     M, N, K, ta, tb = shape

@@ -19,7 +19,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob(out + '/pass*_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        if 'gemm' in r['Kernel_Name']:
+        if 'gemm' in r['Kernel_Name'] and 'split' not in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(agg.items()):
     print('%-28s last-dispatch %.4g  (n=%d)' % (k, v[-1], len(v)))
