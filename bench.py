@@ -55,7 +55,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='GLOBAL batch (strong scaling, the default) or per-GPU batch (--weak)')
     ap.add_argument('--strong', action='store_true', help='(default) shard a GLOBAL batch of --batch over the ranks')
     ap.add_argument('--weak', action='store_true', help='headline = weak scaling (--batch per GPU); the strong variant moves to the side object')
@@ -96,13 +96,35 @@ def cpu_model() -> str:
     return 'unknown CPU'
 
 
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota (a one-GPU box is given a 16-core share of a
+    128-thread host; 128 worker threads on that share run several times slower and noisily)."""
+    n = min(torch.get_num_threads(), len(os.sched_getaffinity(0)))
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(qt, budget_s: float, force_b: int = 0):
     """CPU oracle (port of the reference's execution plan) on this host's cores, SURVEY.md §8(d) / BASELINE.md §4.2:
     forward (eval, no_grad) and forward+backward+CE (train mode), >= 3 timed iterations each, median, at B = 256 or the
     largest batch whose 3+3 iterations fit `budget_s` (calibrated on a B = 8 run)."""
     oracle = importlib.import_module('oracle.qatiger_oracle')
     synth = qt.synth
-    cores = min(torch.get_num_threads(), len(os.sched_getaffinity(0)))
+    cores = host_cores()
     torch.set_num_threads(cores)
     full = synth.CONFIG_2
     P = synth.make_state_dict(full, 713)
@@ -448,9 +470,11 @@ def main():
             'value': round(value, 2), 'unit': 'QA-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 3), 'hip_event_ms': hip_ms, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': DTYPE.get((ops.precision['fwd'], ops.precision['bwd']), f"f32 ({ops.precision['fwd']} fwd / {ops.precision['bwd']} bwd)"),
-            'dtype_note': 'fp32 in, fp32 out, fp32 accumulate everywhere; a GEMM product a*b is evaluated as 3 16-bit MFMA products on hi+lo-split fp32 operands '
-                          '(fp16 parts, 11+11 significand bits, in the forward; bf16 parts, 8+8 bits, ~1.5e-5 relative per product, in the backward whose operands are gradients); '
-                          'logits within 1e-6 of the exact-fp32 kernels; the exact-fp32 figure is in strict_fp32',
+            'dtype_note': 'fp32 in, fp32 out, fp32 accumulate everywhere; a GEMM product a*b is evaluated as 3 fp16 MFMA products on hi+lo-split fp32 operands '
+                          '(11+11 significand bits) in the forward AND the backward: weight operands are scaled by a power of two from max|w|, gradient operands '
+                          'by one from max|dY|, so the parts stay in fp16\'s normal range whatever the magnitude (tests/test_gpu_ops.py: error of the exact-fp32 '
+                          'MFMA kernel at 1e-9 .. 1e5); the exact-fp32 kernels are timed in strict_fp32' if ops.precision['bwd'] == 'f16x3' else
+                          'fp32 in/out/accumulate; GEMM products as 3 16-bit MFMA products on hi+lo-split operands; see ops.precision',
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: train step (fwd + CE + bwd + grad all-reduce + Adam, dropout on) on synthetic '
                                    'CLIP/VGGish/ToMe-shaped features, reference initialisers',

@@ -60,7 +60,10 @@ int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N
                const float* bias, const float* add_src, long ld_add, int relu,
                const float* mask_src, long ld_mask, float mask_scale,
                float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
-               int batch, long a_bs, long b_bs, long c_bs);
+               int batch, long a_bs, long b_bs, long c_bs,
+               const float* a_amax /* nullable: device max|A| (qt_amax_f32); A is scaled by the power of two that puts it in fp16's normal
+                                      range before its split and the result is scaled back: backward GEMMs pass max|dY| here */,
+               const float* b_amax /* the same for B */);
 
 /* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
  * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward
@@ -158,6 +161,9 @@ int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, 
 /* max |x| over an fp32 [R, C] tensor (row pitch ldx elements) into the device float *amax (atomic max on the bit pattern);
  * zero_first != 0 clears *amax first, 0 folds into an earlier maximum. */
 int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first);
+/* the same for n_segments tensors of one flat buffer in one launch: amax[s] = max |flat[offsets[s] .. offsets[s] + counts[s])|
+ * (offsets / counts: device int64 arrays).  Every parameter's scale after an optimizer step. */
+int qt_amax_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments, float* amax);
 /* fp32 [R, C] -> split image: per row and per block of 32 columns one 128-byte line [32 x fp16 hi | 32 x fp16 lo] with
  * hi = fp16(s x), lo = fp16(s x - hi); s = 2^e chosen from *amax (nullable: s = 1) so that s * amax lies in [2^13, 2^14).
  * img: R rows of ld_img_bytes (multiple of 128, >= 4 C).  colsum (nullable): colsum[c] = sum_r x[r, c], the bias gradient of a

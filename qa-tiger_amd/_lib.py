@@ -106,12 +106,13 @@ _i, _l, _f, _u64 = C.c_int, C.c_long, C.c_float, C.c_ulonglong
 # name -> argtypes; every function returns int (0 = ok) except the two noted
 SIGNATURES = {
     'qt_gemm_f32': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _i, _l, _l, _l],
-    'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _i, _l, _l, _l],
+    'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _i, _l, _l, _l, _p],
     'qt_gemm_ps': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
     'qt_gemm_f8': [_p, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
     'qt_quant_fp8': [_p, _p, _l, _l, _i, _p, _p, _l],
     'qt_split_f16': [_p, _p, _l, _l, _i, _p, _p, _l, _p],
     'qt_amax_f32': [_p, _p, _l, _l, _i, _p, _i],
+    'qt_amax_segments': [_p, _p, _p, _p, _i, _p],
     'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_xattn_bwd': [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p],
     'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],

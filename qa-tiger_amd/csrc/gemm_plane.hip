@@ -66,25 +66,6 @@ struct PlaneArgs {
     int debug;                       // QT_PS_DEBUG (profiling probes only): 1 skip the write-out, 2 DMA only for the first step of a tile, 4 no MFMAs
 };
 
-// scale exponent of a tensor whose largest magnitude is `amax`: 2^e * amax lands in [2^13, 2^14) — a factor 4 under
-// fp16's largest finite value (65504) for the rounding of hi, 27 binades above the fp16 subnormal spacing for lo.
-__host__ __device__ inline float qt_plane_scale(float amax) {
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
-    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;     // floor(log2(amax)) for normal floats
-    int e = 13 - ex;
-    e = e > 126 ? 126 : (e < -126 ? -126 : e);
-    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
-}
-
-// e4m3 images: 2^e * amax lands in [2^7, 2^8) (the format's largest finite value is 448)
-__host__ __device__ inline float qt_fp8_scale(float amax) {
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
-    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
-    int e = 7 - ex;
-    e = e > 126 ? 126 : (e < -126 ? -126 : e);
-    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
-}
-
 // one LDS-DMA wave instruction: 64 lanes x 16 B from (sbase + voff[lane]) to LDS bytes [lds_addr, lds_addr + 1024).
 // lds_addr and sbase are wave-uniform (SGPRs).  M0 carries the LDS address; nothing else in this kernel uses M0.
 __device__ __forceinline__ void qt_dma16(unsigned lds_addr, const void* sbase, unsigned voff) {
@@ -688,6 +669,30 @@ __global__ __launch_bounds__(256) void qt_amax_flat_kernel(const float* __restri
 }
 
 static __global__ void qt_zero_n_kernel(float* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0.f; }
+
+// max |x| of many tensors living in one flat buffer (train.FlatParams: every parameter of the model) in ONE launch:
+// segment s = flat[off[s] .. off[s] + cnt[s]); grid = (blocks per segment, segments); amax[s] must be zero on entry.
+__global__ __launch_bounds__(256) void qt_amax_segments_kernel(const float* __restrict__ flat, const long* __restrict__ off, const long* __restrict__ cnt,
+                                                               float* __restrict__ amax) {
+    const int sgm = blockIdx.y;
+    const float* x = flat + off[sgm];
+    const long n = cnt[sgm];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = qt_wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax + sgm), __builtin_bit_cast(unsigned, m));
+}
+
+extern "C" int qt_amax_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments, float* amax) {
+    QT_CHECK_ARG(flat && offsets && counts && amax && n_segments > 0, "qt_amax_segments: bad arguments");
+    QT_CHECK_ARG(n_segments <= 65535, "qt_amax_segments: too many segments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = qt_zero_1d(amax, n_segments, st);
+    if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_amax_segments: zeroing: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(qt_amax_segments_kernel, dim3(8, (unsigned)n_segments), dim3(256), 0, st, flat, offsets, counts, amax);
+    QT_CHECK_LAUNCH("qt_amax_segments");
+    return QT_OK;
+}
 
 extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first) {
     QT_CHECK_ARG(x && amax && R > 0 && C > 0 && ldx >= C, "qt_amax_f32: bad arguments");

@@ -56,6 +56,8 @@ struct GemmArgs {          // identical to gemm.hip
     int tiles_m;
     int batch; long a_bs, b_bs, c_bs;   // batched launch (one problem per attention head): count and element strides
     float* a_colsum;          // transA only: a_colsum[m] += sum_k A[k,m]  (bias gradient riding on the dW GEMM)
+    const float* a_amax;      // nullable: device max|A|; A is multiplied by the power of two that puts it in fp16's normal range before its split
+    const float* b_amax;      // the same for B (products whose gradient operand is B: dV = P^T dO, dW_k = q^T dU)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -214,31 +216,35 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
             else dst[j] = (kt + j < kend) ? *reinterpret_cast<const float*>(b + (long)j * ld * 4) : 0.f;
         }
     };
-    auto store_kc = [&](u16* hi_img, u16* lo_img, const auto& src) {
+    // sA: the gradient operand's power-of-two scale (1 when the operand is taken as it is).  Backward GEMMs hand in max|dY|
+    // (a_amax): dY * sA sits in fp16's normal range whatever its magnitude, so the fp16 parts keep 11 + 11 bits there too.
+    const float sA = p.a_amax ? qt_plane_scale(*p.a_amax) : 1.0f;
+    const float sB = p.b_amax ? qt_plane_scale(*p.b_amax) : 1.0f;
+    auto store_kc = [&](u16* hi_img, u16* lo_img, const auto& src, float sc) {
         constexpr int L = sizeof(src) / sizeof(src[0]) / 4;
 #pragma unroll
         for (int it = 0; it < L; ++it) {
             const int idx = tid + it * NT;
             const int row = kc_row(idx), kq = idx & 7;
             uint2 vh, vl;
-            split_pair<HT>(src[it * 4 + 0], src[it * 4 + 1], vh.x, vl.x);
-            split_pair<HT>(src[it * 4 + 2], src[it * 4 + 3], vh.y, vl.y);
+            split_pair<HT>(src[it * 4 + 0] * sc, src[it * 4 + 1] * sc, vh.x, vl.x);
+            split_pair<HT>(src[it * 4 + 2] * sc, src[it * 4 + 3] * sc, vh.y, vl.y);
             *reinterpret_cast<uint2*>(hi_img + row * SLD + kq * 4) = vh;
             if constexpr (HT < 2) *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
         }
     };
     float csum = 0.f;                                               // this thread's share of a_colsum (TA only)
     bool do_csum = false;
-    auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src) {
+    auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src, float sc) {
         constexpr int KN = sizeof(src) / sizeof(src[0]);
         const int col = tid % edge, kb = (tid / edge) * KN;
 #pragma unroll
         for (int e = 0; e < KN / 8; ++e) {
             uint4 vh, vl;
-            split_pair<HT>(src[e * 8 + 0], src[e * 8 + 1], vh.x, vl.x);
-            split_pair<HT>(src[e * 8 + 2], src[e * 8 + 3], vh.y, vl.y);
-            split_pair<HT>(src[e * 8 + 4], src[e * 8 + 5], vh.z, vl.z);
-            split_pair<HT>(src[e * 8 + 6], src[e * 8 + 7], vh.w, vl.w);
+            split_pair<HT>(src[e * 8 + 0] * sc, src[e * 8 + 1] * sc, vh.x, vl.x);
+            split_pair<HT>(src[e * 8 + 2] * sc, src[e * 8 + 3] * sc, vh.y, vl.y);
+            split_pair<HT>(src[e * 8 + 4] * sc, src[e * 8 + 5] * sc, vh.z, vl.z);
+            split_pair<HT>(src[e * 8 + 6] * sc, src[e * 8 + 7] * sc, vh.w, vl.w);
             *reinterpret_cast<uint4*>(hi_img + col * SLD + kb + e * 8) = vh;
             if constexpr (HT < 2) *reinterpret_cast<uint4*>(lo_img + col * SLD + kb + e * 8) = vl;
         }
@@ -255,14 +261,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     auto sstore = [&](int buf, const auto& xa, const auto& xb) {
         u16* b0 = smem + buf * STAGE;
         if (TA) {
-            store_ks(b0, b0 + A_IMG, BM, xa);
+            store_ks(b0, b0 + A_IMG, BM, xa, sA);
             if (do_csum) {                                          // K-tail and out-of-range rows were loaded as zeros
                 constexpr int KN = sizeof(xa) / sizeof(xa[0]);
 #pragma unroll
                 for (int j = 0; j < KN; ++j) csum += xa[j];
             }
-        } else store_kc(b0, b0 + A_IMG, xa);
-        if (TB) store_kc(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, xb); else store_ks(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, BN, xb);
+        } else store_kc(b0, b0 + A_IMG, xa, sA);
+        if (TB) store_kc(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, xb, sB); else store_ks(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, BN, xb, sB);
     };
     auto compute = [&](int cur) {
         const u16* b0 = smem + cur * STAGE;
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         const int n = ncol0 + j * 32;
         bias_v[j] = (p.bias && first_split && n < p.N) ? p.bias[n] : 0.f;
     }
+    const float alpha_s = p.alpha / (sA * sB);
     auto epilogue = [&](auto ADD, auto FULL) {
         constexpr bool has_add = decltype(ADD)::value, full = decltype(FULL)::value;
         const bool atomic = p.split_k > 1;
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                         static_for<WNT>([&](auto J) {
                             constexpr int j = decltype(J)::value;
                             if (ncol0 + j * 32 < p.N) {
-                                float v = p.alpha * acc[i][j][e] + bias_v[j];
+                                float v = alpha_s * acc[i][j][e] + bias_v[j];
                                 if (has_add) v += addv[e8][j];
                                 if (atomic) { atomicAdd(crow + j * 32, v); return; }
                                 if (act == 1) v = fmaxf(v, 0.f);
@@ -458,7 +465,8 @@ static void launch_x3(const GemmArgs& a, int transA, int transB, dim3 grid, hipS
 #define QT_X3(TA_, TB_)                                                                                           \
     do {                                                                                                          \
         auto kern = qt_gemm_x3_kernel<WMT, WNT, NWM, NWN, PREF, TA_, TB_, HT>;                                    \
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        static bool attr_set = false;   /* once per instance, not per launch (and never inside a stream capture) */ \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);                                                     \
     } while (0)
     if (!transA && transB) QT_X3(false, true);
@@ -500,7 +508,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
                           const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
-                          int batch, long a_bs, long b_bs, long c_bs) {
+                          int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_x3: bad problem");
     QT_CHECK_ARG(!a_colsum || transA, "qt_gemm_x3: a_colsum needs transA (A given as [K,M])");
     if (batch < 1) batch = 1;
@@ -530,7 +538,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
-    a.a_colsum = a_colsum; a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
+    a.a_colsum = a_colsum; a.a_amax = a_amax; a.b_amax = b_amax; a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
 
@@ -583,7 +591,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         }
     }
     if (a_colsum) {
-        hipError_t e = hipMemsetAsync(a_colsum, 0, sizeof(float) * (size_t)M, st);
+        hipError_t e = qt_zero_1d(a_colsum, M, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
     }
     QT_CHECK_ARG(tiles < (1L << 31), "qt_gemm_x3: grid too large");

@@ -35,7 +35,7 @@ extern "C" int qt_colsum(void* stream, const float* x, long ldx, int M, int N, f
     QT_CHECK_ARG(x && out && M > 0 && N > 0 && ldx >= N, "qt_colsum: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+        hipError_t e = qt_zero_1d(out, N, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_colsum: memset: %s", hipGetErrorString(e));
     }
     const int col_blocks = (N + 255) / 256;

@@ -209,8 +209,8 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
         if (dx[i]) QT_CHECK_ARG(qt_aligned16(dx[i]) && lddx[i] % 4 == 0, "qt_add_ln_bwd: dx %d alignment", i);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dgamma, 0, sizeof(float) * D, st);
-    if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, sizeof(float) * D, st);
+    hipError_t e = qt_zero_1d(dgamma, D, st);
+    if (e == hipSuccess) e = qt_zero_1d(dbeta, D, st);
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_add_ln_bwd: memset: %s", hipGetErrorString(e));
     const int blocks = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);   // 2048 x 4 waves: 32 waves per CU
     hipLaunchKernelGGL(qt_add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -64,15 +64,55 @@ __device__ inline float qt_wave_max(float v) {
 
 static inline bool qt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- per-tensor power-of-two scales of 16-bit / 8-bit operand parts -------------------------------------------
+// fp16 (hi, lo) parts: 2^e * amax lands in [2^13, 2^14) — a factor 4 under fp16's largest finite value (65504) for the rounding
+// of hi, 27 binades above the fp16 subnormal spacing for lo: the parts keep 11 + 11 significand bits whatever the tensor's
+// magnitude (gradients of 1e-9, weights of 1e-4, activations of 1e5).
+__host__ __device__ inline float qt_plane_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;     // floor(log2(amax)) for normal floats
+    int e = 13 - ex;
+    e = e > 126 ? 126 : (e < -126 ? -126 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+// e4m3 images: 2^e * amax lands in [2^7, 2^8) (the format's largest finite value is 448)
+__host__ __device__ inline float qt_fp8_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int e = 7 - ex;
+    e = e > 126 ? 126 : (e < -126 ? -126 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+
 // ---- zero a [M, N] region with row pitch ldc -----------------------------------
-// Contiguous regions use a 1-D memset; strided ones a small kernel.  (hipMemset2DAsync is avoided: its graph-capture
+// Contiguous regions use the 1-D zeroing kernel; strided ones a small 2-D kernel.  (hipMemset2DAsync is avoided: its graph-capture
 // node faulted on replay at the primary shapes, and every entry point of this library is meant to be capturable.)
 static __global__ __launch_bounds__(256) void qt_zero2d_kernel(float* __restrict__ C, long ldc, int M, int N) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < (long)M * N) { const long r = i / N; C[r * ldc + (i - r * N)] = 0.f; }
 }
+// (no hipMemsetAsync / hipMemset2DAsync anywhere in the library: runtime blit nodes inside a captured graph are the class of
+// operation the ROCm 7.2 replay fault of round 1 was narrowed down to; every zeroing is an ordinary kernel of this library.)
+static __global__ __launch_bounds__(256) void qt_zero1d_kernel(float4* __restrict__ p4, long n4, float* __restrict__ tail, int ntail) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+static inline hipError_t qt_zero_1d(float* p, long n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if ((((uintptr_t)p) & 15u) != 0) {               // unaligned start: the 2-D kernel handles any pointer
+        hipLaunchKernelGGL(qt_zero2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, 1, (int)n);
+        return hipGetLastError();
+    }
+    const long n4 = n >> 2;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(qt_zero1d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<float4*>(p), n4, p + (n4 << 2), (int)(n & 3));
+    return hipGetLastError();
+}
 static inline hipError_t qt_zero_2d(float* C, long ldc, int M, int N, hipStream_t st) {
-    if (ldc == N) return hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)N, st);
+    if (ldc == N && (long)M * N < (1L << 31)) return qt_zero_1d(C, (long)M * N, st);
     const long n = (long)M * N;
     hipLaunchKernelGGL(qt_zero2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, C, ldc, M, N);
     return hipGetLastError();

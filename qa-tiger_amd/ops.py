@@ -31,13 +31,13 @@ if _os.environ.get('QT_GEMM', '').lower() == 'fp32':
 elif _os.environ.get('QT_GEMM', '').lower() == 'bf16x1':
     precision = {'fwd': 'bf16x1', 'bwd': 'bf16x1'}
 else:
-    precision = {'fwd': 'f16x3', 'bwd': 'bf16x3'}
+    precision = {'fwd': 'f16x3', 'bwd': 'f16x3'}     # bwd: fp16 parts too, on dY scaled by its max|dY| (LinearFn.backward)
 # Pre-split operand pipeline (csrc/gemm_plane.hip): Linear layers whose shapes fit run on split images — the input is split once
 # (and reused by every layer that reads it and by the dW GEMM of the backward), weights are split once per optimizer step, the
 # gradient dY is measured (max|dY|), scaled into fp16's normal range and split once for the dX and dW GEMMs: fp32-equivalent
 # products (3 fp16 MFMAs on 11+11-bit parts) in the forward AND the backward.  QT_PLANE=0 keeps every GEMM on the
 # split-in-the-consumer kernels (gemm_split.hip: fp16 parts forward, bf16 parts backward).
-plane = _os.environ.get('QT_PLANE', '1') != '0'      # and precision['fwd'] == 'f16x3', checked per call: bench.py switches modes at run time
+plane = _os.environ.get('QT_PLANE', '0') != '0'      # and precision['fwd'] == 'f16x3', checked per call: bench.py switches modes at run time
 weights_epoch = 0          # bumped whenever parameter memory is rewritten behind autograd's back (train.FusedAdam.step)
 _HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'bf16x1': 3, 'f16x3_t128': 16, 'bf16x3_t128': 17, 'f16x3_t256': 32, 'bf16x3_t256': 33}   # _tNNN: force a tile (A/B testing)
 
@@ -158,8 +158,10 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
          bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: bool = False,
          mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
          accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, mode: str = 'fp32',
-         a_colsum: Optional[Tensor] = None, batch: Optional[Tuple[int, int, int, int]] = None) -> Tensor:
-    """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3."""
+         a_colsum: Optional[Tensor] = None, batch: Optional[Tuple[int, int, int, int]] = None,
+         a_amax: Optional[Tensor] = None, b_amax: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3.
+    a_amax / b_amax (split modes only): device max|a| / max|b|; that operand is scaled into fp16's normal range before its split (gradient operands)."""
     a, b = as2d(a), as2d(b)
     _dev(a, b, bias, add, mask_src, out)
     if mode == 'fp8':                                   # configs[4]: only the Linear projections run on fp8 images (LinearFn);
@@ -189,7 +191,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     btail = (int(nb), int(a_bs), int(b_bs), int(c_bs))
     if mode != 'fp32':
         rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), mode) + ((nb,) if nb > 1 else ()),
-                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail))
+                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail, _ptr(a_amax), _ptr(b_amax)))
         if rc == 0:
             return out
         if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
@@ -432,7 +434,8 @@ def weight_image_fp8(weight: Tensor) -> Optional[SplitImage]:
 
 def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
     cached = getattr(x, '_qt_img8', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape \
+            and not torch.cuda.is_current_stream_capturing():
         return cached[1]
     img = quant_fp8(x2.detach())
     x._qt_img8 = ((x._version, x.data_ptr()), img)
@@ -443,12 +446,63 @@ def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     """Split image of an activation (x2 = the [rows, k_in] view of x), made once per tensor object: the layers that read the
     same tensor (the three in-projections of AVQCrossAttn, ...) and the dW GEMM of the backward share it."""
     cached = getattr(x, '_qt_img', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
+    # (while a HIP graph is being captured the split must be IN the graph: a cached image would freeze the warm-up batch into it)
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape \
+            and not torch.cuda.is_current_stream_capturing():
         return cached[1]
     with torch.no_grad():
         img = split_image(x2.detach())
     x._qt_img = ((x._version, x.data_ptr()), img)
     return img
+
+
+robust_range = _os.environ.get('QT_ROBUST_RANGE', '0') != '0'   # also measure max|x| of every Linear INPUT (one extra read of it per layer)
+
+
+def weight_amax(weight: Tensor) -> Optional[Tensor]:
+    """Device max|w| of the parameter a Linear weight (or a row slice of one) belongs to: the weight operand is scaled by the
+    matching power of two before its fp16 split, so weights of any magnitude (1e-4 after weight decay, ...) keep 11 + 11 bits.
+    With train.FlatParams every parameter's maximum comes from ONE launch per optimizer step (`_qt_amax_view`); otherwise it is
+    measured once per parameter version and cached on the parameter."""
+    if precision['fwd'] != 'f16x3':
+        return None
+    base = weight._base if weight._base is not None else weight
+    view = getattr(base, '_qt_amax_view', None)
+    if view is not None:
+        flat = base._qt_flat
+        if flat.amax_epoch != weights_epoch or getattr(base, '_qt_amax_ver', -1) != base._version:
+            flat.refresh_amax()
+        return view
+    key = (base._version, weights_epoch, base.data_ptr())
+    cached = getattr(base, '_qt_wamax', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = (key, amax_of(base.detach().reshape(-1, base.shape[-1]) if base.dim() > 1 else base.detach().reshape(1, -1)))
+        base._qt_wamax = cached
+    return cached[1]
+
+
+def act_amax(x: Tensor, x2: Tensor) -> Optional[Tensor]:
+    """max|x| of a Linear input, only in the robust-range mode (activations beyond fp16's range, e.g. |x| ~ 1e5)."""
+    if not robust_range or precision['fwd'] != 'f16x3':
+        return None
+    cached = getattr(x, '_qt_xamax', None)
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and not torch.cuda.is_current_stream_capturing():
+        return cached[1]
+    am = amax_of(x2.detach())
+    x._qt_xamax = ((x._version, x.data_ptr()), am)
+    return am
+
+
+def grad_amax(dy: Tensor, g2: Optional[Tensor] = None) -> Optional[Tensor]:
+    """Device max|dY| for the scaled fp16 split of a backward GEMM's gradient operand (None in the modes that do not need it).
+    A producer that has already measured it tags the tensor (`dy._qt_amax`); otherwise one streaming pass (qt_amax_f32)."""
+    if precision['bwd'] != 'f16x3':
+        return None
+    tag = getattr(dy, '_qt_amax', None)
+    if tag is not None:
+        return tag
+    return amax_of(dy if g2 is None else g2)
 
 
 class LinearFn(torch.autograd.Function):
@@ -463,8 +517,6 @@ class LinearFn(torch.autograd.Function):
         if precision['fwd'] == 'fp8':
             # BASELINE configs[4]: projection GEMMs on fp8 MFMA (forward only; the router / Gaussian / softmax / LayerNorm
             # statistics and every small GEMM stay in fp32 — SURVEY.md Appendix E)
-            if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-                raise _lib.QTError("precision 'fp8' (BASELINE configs[4]) is a forward-only mode: run it under torch.no_grad()")
             if x2.shape[0] >= 256 and weight.shape[0] >= 128 and weight.shape[1] % 128 == 0:
                 wq = weight_image_fp8(weight)
                 if wq is not None:
@@ -479,7 +531,10 @@ class LinearFn(torch.autograd.Function):
                 y = gemm_ps(ximg, wimg, bias=bias, add=residual, relu=int(relu), drop_p=drop_p, seed=seed)
         if y is None:
             ximg = wimg = None
-            y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'])
+            wam = weight_amax(weight) if weight.shape[1] % 4 == 0 else None
+            y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'],
+                     a_amax=act_amax(x, x2), b_amax=wam)
+            ctx.wam = wam
         # the plane path saves the input's IMAGE (same bytes) for the dW GEMM, not the fp32 rows
         ctx.save_for_backward(x2 if ximg is None else ximg.data, weight, y if relu else None)
         ctx.used_plane = ximg is not None
@@ -526,18 +581,19 @@ class LinearFn(torch.autograd.Function):
                 if wgv is not None:
                     dw = wgv[:]
         else:
+            gam = grad_amax(dy, g)                          # max|dY|: the gradient operand's scale for both GEMMs
             if ctx.needs_input_grad[0]:
                 if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], weight.shape[1]):
-                    gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True)   # dx stays None
+                    gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True, a_amax=gam, b_amax=ctx.wam)   # dx stays None
                     link.buf = None
                 else:
-                    dx = gemm(g, weight, trans_b=False, mode=precision['bwd']).reshape(shape)
+                    dx = gemm(g, weight, trans_b=False, mode=precision['bwd'], a_amax=gam, b_amax=ctx.wam).reshape(shape)
             if ctx.needs_input_grad[1]:
                 if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
                     bgv = _claim_grad_view(b_param)
                     db = bgv[:] if bgv is not None else torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
                 wgv = _claim_grad_view(w_param)
-                dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db,
+                dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db, a_amax=gam,
                           out=None if wgv is None else wgv[:])                                   # [N_out, K_in] = g^T x
             elif want_db:
                 db = colsum(g)
@@ -553,6 +609,8 @@ class LinearFn(torch.autograd.Function):
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False, drop_p: float = 0.0,
            seed: int = 0, residual: Optional[Tensor] = None, grad_premasked: bool = False,
            link: Optional[GradLink] = None) -> Tensor:
+    if precision['fwd'] == 'fp8' and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise _lib.QTError("precision 'fp8' (BASELINE configs[4]) is a forward-only mode: run it under torch.no_grad()")
     return LinearFn.apply(x, weight, bias, relu, drop_p, seed, residual, grad_premasked, link)
 
 
@@ -668,13 +726,14 @@ class HeadExpandFn(torch.autograd.Function):
         M, E = q2.shape
         D, dh = w2.shape[1], E // H
         du = as2d(du.contiguous())
+        gam = grad_amax(du)
         dq = dw = None
         if ctx.needs_input_grad[0]:
             dq = torch.empty_like(q2)
-            gemm(du[:, :D], w2[:dh], trans_b=True, out=dq[:, :dh], batch=(H, D, dh * D, dh), mode=precision['bwd'])
+            gemm(du[:, :D], w2[:dh], trans_b=True, out=dq[:, :dh], batch=(H, D, dh * D, dh), mode=precision['bwd'], a_amax=gam)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w2)
-            gemm(q2[:, :dh], du[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'])
+            gemm(q2[:, :dh], du[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'], b_amax=gam)
         return dq, dw, None
 
 
@@ -701,13 +760,14 @@ class HeadContractFn(torch.autograd.Function):
         D = w2.shape[1]
         dh = w2.shape[0] // H
         do = as2d(do.contiguous())
+        gam = grad_amax(do)
         dc = dw = None
         if ctx_.needs_input_grad[0]:
             dc = torch.empty_like(c2)
-            gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'])
+            gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'], a_amax=gam)
         if ctx_.needs_input_grad[1]:
             dw = torch.empty_like(w2)
-            gemm(do[:, :dh], c2[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'])
+            gemm(do[:, :dh], c2[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'], a_amax=gam)
         return dc, dw, None
 
 
@@ -1031,10 +1091,11 @@ def eval_counts(logits: Tensor, label: Tensor, qtype: Optional[Tensor] = None, n
 # (TSPM's nn.MultiheadAttention(512, nhead=1), reference src/models/tspm.py:20-21, 194), and the head-averaged
 # attention weights nn.MultiheadAttention returns (tspm.py:99-100)
 # --------------------------------------------------------------------------- #
-def _batched(a: Tensor, b: Tensor, out: Tensor, nb: int, a_bs: int, b_bs: int, c_bs: int, trans_a=False, trans_b=True, mode='fp32'):
+def _batched(a: Tensor, b: Tensor, out: Tensor, nb: int, a_bs: int, b_bs: int, c_bs: int, trans_a=False, trans_b=True, mode='fp32',
+             a_amax=None, b_amax=None):
     """`nb` equal problems; `a`, `b`, `out` are views of the FIRST one (unit column stride), the others follow at the
     given element strides."""
-    return gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, mode=mode, batch=(nb, a_bs, b_bs, c_bs))
+    return gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, mode=mode, batch=(nb, a_bs, b_bs, c_bs), a_amax=a_amax, b_amax=b_amax)
 
 
 class BmmAttentionFn(torch.autograd.Function):
@@ -1087,23 +1148,25 @@ class BmmAttentionFn(torch.autograd.Function):
             _lib.check(lib.qt_mask_grad(_stream(), _ptr(P), Lk, None, 0, float(drop_p), C.c_ulonglong(seed), _ptr(Y), Lk, n_items * Lq, Lk), 'qt_mask_grad')
         else:
             Y = P
+        gam_o = grad_amax(dO)                                        # gradient operands are scaled by their max before the fp16 split
         for lo, hi, sh in parts:
             nb = hi - lo
             # dV[kv item] = Y^T dO ;  dY = dO V^T
             _batched(Y[lo * Lq:lo * Lq + Lq], dO[lo * Lq:lo * Lq + Lq], dkb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, v_col:v_col + E],
-                     nb, Lq * Lk, Lq * E, Lk * _ld(dkb), trans_a=True, trans_b=False, mode=mode_b)
+                     nb, Lq * Lk, Lq * E, Lk * _ld(dkb), trans_a=True, trans_b=False, mode=mode_b, b_amax=gam_o)
             _batched(dO[lo * Lq:lo * Lq + Lq], kb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, v_col:v_col + E], dY[lo * Lq:lo * Lq + Lq],
-                     nb, Lq * E, Lk * _ld(kb), Lq * Lk, trans_b=True, mode=mode_b)
+                     nb, Lq * E, Lk * _ld(kb), Lq * Lk, trans_b=True, mode=mode_b, a_amax=gam_o)
         dS = dY
         _lib.check(lib.qt_softmax_bwd(_stream(), _ptr(dY), Lk, _ptr(P), Lk, n_items * Lq, Lk, scale, float(drop_p), C.c_ulonglong(seed),
                                       _ptr(dS), Lk), 'qt_softmax_bwd')
+        gam_s = grad_amax(dS)
         for lo, hi, sh in parts:
             nb = hi - lo
             # dQ = dS K ;  dK[kv item] = dS^T Q
             _batched(dS[lo * Lq:lo * Lq + Lq], kb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, k_col:k_col + E], dqb[lo * Lq:lo * Lq + Lq, q_col:q_col + E],
-                     nb, Lq * Lk, Lk * _ld(kb), Lq * _ld(dqb), trans_b=False, mode=mode_b)
+                     nb, Lq * Lk, Lk * _ld(kb), Lq * _ld(dqb), trans_b=False, mode=mode_b, a_amax=gam_s)
             _batched(dS[lo * Lq:lo * Lq + Lq], qb[lo * Lq:lo * Lq + Lq, q_col:q_col + E], dkb[(lo + sh) * Lk:(lo + sh) * Lk + Lk, k_col:k_col + E],
-                     nb, Lq * Lk, Lq * _ld(qb), Lk * _ld(dkb), trans_a=True, trans_b=False, mode=mode_b)
+                     nb, Lq * Lk, Lq * _ld(qb), Lk * _ld(dkb), trans_a=True, trans_b=False, mode=mode_b, a_amax=gam_s)
         return (dqb.reshape(qshape), None if packed else dkb.reshape(kvshape)) + (None,) * 10
 
 

@@ -58,11 +58,28 @@ class FlatParams:
                 view.copy_(p.data)
                 p.data = view                     # the module now computes from the flat buffer
         self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
-        for p, gv in zip(self.params, self.grad_views):
+        # max|w| of every parameter (the fp16 split of a weight operand is scaled by it): one launch per optimizer step
+        self.amax = torch.zeros(len(self.params), device=dev, dtype=dt)
+        self._seg_off = torch.tensor(self.offsets, dtype=torch.int64, device=dev)
+        self._seg_cnt = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+        self.amax_epoch = None
+        for i, (p, gv) in enumerate(zip(self.params, self.grad_views)):
             p._qt_gv = gv                          # ops.LinearFn writes dW / db straight into the flat gradient buffer
+            if dev.type == 'cuda':
+                p._qt_amax_view = self.amax[i:i + 1]
+                p._qt_flat = self
 
     def numel(self) -> int:
         return sum(p.numel() for p in self.params)
+
+    def refresh_amax(self) -> None:
+        """max|w| of every parameter in one launch (include/qatiger.h qt_amax_segments)."""
+        lib = ops._lib.load()
+        ops._lib.check(lib.qt_amax_segments(ops._stream(), ops._ptr(self.flat), ops._ptr(self._seg_off), ops._ptr(self._seg_cnt),
+                                            len(self.params), ops._ptr(self.amax)), 'qt_amax_segments')
+        self.amax_epoch = ops.weights_epoch
+        for p in self.params:
+            p._qt_amax_ver = p._version             # (a load_state_dict / copy_ into the parameters bumps the version: re-measure)
 
     def check(self) -> None:
         """The parameters must still BE views of the flat buffer.  `model.to(...)`, `model.float()`, `load_state_dict(...,

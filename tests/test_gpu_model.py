@@ -25,7 +25,7 @@ DEV = 'cuda'
 GATE = 1e-3
 EXPECT = 1e-4
 GRAD_L2 = 5e-3
-GRAD_MEDIAN = 2e-4
+GRAD_MEDIAN = 5e-5
 
 
 def l2rel(a, b):
@@ -303,6 +303,37 @@ def test_training_soak_at_real_dims(qt, synth):
     for t in (eng.flat.flat, eng.flat.grad, eng.optim.exp_avg, eng.optim.exp_avg_sq):
         assert bool(torch.isfinite(t).all())
     assert eng.optim.step_count == 40
+
+
+def test_range_guard_large_activations_and_tiny_weights(qt, synth, oracle):
+    """fp16-split GEMMs outside fp16's comfortable range: features of magnitude ~1e5 and projection weights of
+    ~1e-4.  Weight operands are always scaled by max|w| (free: one launch per optimizer step), so tiny weights cost nothing.
+    Activations beyond fp16's range need `ops.robust_range` (max|x| of every Linear input: one extra read each): with it the
+    logits stay within 1e-4 of the oracle; WITHOUT it the overflow shows as non-finite logits — never as plausible wrong numbers."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 8})
+    P = synth.make_state_dict(cfg, 713)
+    inp = synth.make_inputs(cfg, 713)
+    for n in ('audio_proj.proj.weight', 'video_proj.proj.weight', 'patch_proj.proj.weight'):
+        P[n] = P[n] * 1e-3                                  # ~1e-4 .. 1e-5 weights
+    big = {k: (v * 1e5 if k in ('audio', 'video', 'patch') else v) for k, v in inp.items()}
+    model = qt.QA_TIGER(**cfg.model_kwargs())
+    model.load_state_dict(P, strict=True)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        ref = oracle.qa_tiger_forward(P, big, cfg.K, cfg.k).numpy()
+        keep = qt.ops.robust_range
+        try:
+            qt.ops.robust_range = True
+            out = model(to_dev(big))['out'].cpu().numpy()
+            qt.ops.robust_range = False
+            raw = model(to_dev(big))['out'].cpu().numpy()
+        finally:
+            qt.ops.robust_range = keep
+    assert np.isfinite(ref).all()
+    e = rel_err(out, ref)
+    print(f'range guard: robust mode rel logit err {e:.2e}; default mode finite: {bool(np.isfinite(raw).all())}')
+    assert e < 1e-4 and (out.argmax(-1) == ref.argmax(-1)).all()
+    assert not np.isfinite(raw).all() or rel_err(raw, ref) < 1e-4       # loud (non-finite) or right — never silently wrong
 
 
 def test_cpu_tensors_fail_loudly(qt, synth):

@@ -501,3 +501,23 @@ def test_fused_adam_matches_torch(ops):
         opt.step()
         ops.adam_step_(p, g, m, v, step, 1e-4, (0.95, 0.999), 1e-8)
         assert float((p - ref.detach()).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize('sa,sb,ta,tb', [(1e-7, 1.0, False, True), (3e-9, 2e-5, False, False), (1e-6, 1.0, True, False), (1e5, 1e-4, False, True)])
+def test_gemm_f16x3_scaled_operands_are_fp32_equivalent(ops, sa, sb, ta, tb):
+    """The split-in-the-consumer kernel with per-tensor power-of-two scales (qt_gemm_x3 a_amax / b_amax): gradient-like (1e-7 .. 1e-9),
+    tiny-weight (1e-4) and huge (1e5) operands give the error of the exact-fp32 MFMA kernel; unscaled, the same operands lose
+    their low parts to fp16 subnormals or overflow.  This is what makes the BACKWARD GEMMs fp32-equivalent."""
+    M, N, K = 384, 256, 512
+    g = torch.Generator().manual_seed(91)
+    a = (torch.randn((K, M) if ta else (M, K), generator=g) * sa).to(DEV)
+    b = (torch.randn((N, K) if tb else (K, N), generator=g) * sb).to(DEV)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb, mode='f16x3', a_amax=ops.amax_of(a), b_amax=ops.amax_of(b))
+    e = rel(out, ref)
+    e32 = rel(ops.gemm(a, b, trans_a=ta, trans_b=tb, mode='fp32'), ref)
+    raw = ops.gemm(a, b, trans_a=ta, trans_b=tb, mode='f16x3')
+    e_raw = rel(raw, ref) if bool(torch.isfinite(raw).all()) else float('inf')
+    print(f'scales {sa:g} x {sb:g}: scaled f16x3 {e:.2e}, exact fp32 {e32:.2e}, unscaled f16x3 {e_raw:.2e}')
+    assert e < 2e-6 and e < 4 * e32 + 5e-7
+    assert e_raw > 10 * e
