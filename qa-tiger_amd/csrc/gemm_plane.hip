@@ -694,11 +694,29 @@ extern "C" int qt_amax_segments(void* stream, const float* flat, const long* off
     return QT_OK;
 }
 
+// any row length / alignment (the head's [B, 42] logit gradients, ...)
+__global__ __launch_bounds__(256) void qt_amax_scalar_kernel(const float* __restrict__ x, long ldx, long R, int C, float* __restrict__ amax) {
+    const long total = R * C;
+    float m = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / C;
+        m = fmaxf(m, fabsf(x[row * ldx + (idx - row * C)]));
+    }
+    m = qt_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
+}
+
 extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first) {
     QT_CHECK_ARG(x && amax && R > 0 && C > 0 && ldx >= C, "qt_amax_f32: bad arguments");
-    QT_CHECK_ARG(C % 4 == 0 && ldx % 4 == 0 && qt_aligned16(x), "qt_amax_f32: rows must be 16-byte aligned (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
     if (zero_first) hipLaunchKernelGGL(qt_zero_n_kernel, dim3(1), dim3(64), 0, st, amax, 1);
+    if (!(C % 4 == 0 && ldx % 4 == 0 && qt_aligned16(x))) {
+        long blocks = (R * C + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(qt_amax_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax);
+        QT_CHECK_LAUNCH("qt_amax_f32");
+        return QT_OK;
+    }
     const long n4 = R * (C >> 2);
     long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
     if (blocks > 4096) blocks = 4096;
