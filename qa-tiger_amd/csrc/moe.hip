@@ -47,11 +47,15 @@ __global__ __launch_bounds__(256) void qt_moe_router_fwd_kernel(
     const float ex = lane < K ? expf(lg - mx) : 0.f;
     const float pr = ex / qt_wave_sum(ex);
     if (lane < K) probs[(long)b * K + lane] = pr;
-    // rank = number of experts that sort before this one (descending; lower index first on ties)
+    // rank = number of experts that sort before this one (descending; lower index first on ties).  Non-finite router
+    // outputs (an overflowed or NaN input upstream) must still give a PERMUTATION of the experts: the indices written below
+    // address memory in qt_moe_coef_fwd / the backward, so NaNs are ranked as equal lowest values instead of comparing false
+    // against everything (which left slots unwritten and sent garbage indices downstream: a GPU memory fault).
+    const float key = (pr == pr) ? pr : -1.0f;
     int rank = 0;
     for (int e = 0; e < K; ++e) {
-        const float pe = __shfl(pr, e, 64);
-        rank += (pe > pr || (pe == pr && e < lane)) ? 1 : 0;
+        const float pe = __shfl(key, e, 64);
+        rank += (pe > key || (pe == key && e < lane)) ? 1 : 0;
     }
     const bool sel = lane < K && rank < k;
     const float denom = qt_wave_sum(sel ? pr : 0.f);
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(256) void qt_moe_coef_fwd_kernel(
     float* cr = coef + row * K;
     for (int e = 0; e < K; ++e) cr[e] = 0.f;
     for (int i = 0; i < k; ++i) {
-        const int e = (int)topk_inds[(long)src * k + i];
+        int e = (int)topk_inds[(long)src * k + i];
+        e = e < 0 ? 0 : (e >= K ? K - 1 : e);               // indices come from device memory: never address outside the row
         const float val = topk_probs[(long)b * k + i] * gauss[((long)b * k + i) * T + t];
         cr[e] += val;                                        // experts of one sample are distinct: no aliasing
     }
