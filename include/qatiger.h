@@ -63,7 +63,8 @@ int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N
                int batch, long a_bs, long b_bs, long c_bs,
                const float* a_amax /* nullable: device max|A| (qt_amax_f32); A is scaled by the power of two that puts it in fp16's normal
                                       range before its split and the result is scaled back: backward GEMMs pass max|dY| here */,
-               const float* b_amax /* the same for B */);
+               const float* b_amax /* the same for B */,
+               float* c_amax /* nullable, non-split-K launches: max|C| record of the values written — the next layer's max|dY| for free */);
 
 /* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
  * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward
@@ -86,7 +87,8 @@ int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
                 float* dk, long lddk, float* dv, long lddv,
                 int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
                 float scale, float drop_p, unsigned long long seed,
-                const float* o_fwd, const float* lse, float* delta_ws);
+                const float* o_fwd, const float* lse, float* delta_ws,
+                float* g_amax /* nullable: max|dq,dk,dv| record, written by the MFMA kernels only: the call then returns 1 instead of 0 */);
 
 /* Few-query attention with the K/V projections folded away (modules.py:562 TempMoE.qst_attn, Lq=1;
  * modules.py:692-698 PatchSelecter.crs_attn, Lq=2).  u = W_k,h^T q'_h per (query, head) is the "query",
@@ -100,7 +102,7 @@ int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, const float
 int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
                  const float* ctx, const float* lse, const float* asum, const float* dctx, const float* dasum,
                  int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
-                 float* du, float* dx);
+                 float* du, float* dx, float* dx_amax /* nullable: max|dx| record */);
 
 /* y = LayerNorm(sum_i sx[i] * dropout_i(x[i])) (+ optional ReLU on y); n_add <= 4.
  * Replaces modules.py:223-229, 233-235, 344-346, 603, 612, 713-716.
@@ -158,11 +160,12 @@ int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, 
 /* ---- pre-split operands (csrc/gemm_plane.hip): the same Linear / projection GEMMs and their backward, on operands whose
  * fp32 -> (hi, lo) fp16 split was done ONCE by a producer pass instead of inside every tile of the GEMM. ---- */
 
-/* max |x| over an fp32 [R, C] tensor (row pitch ldx elements) into the device float *amax (atomic max on the bit pattern);
- * zero_first != 0 clears *amax first, 0 folds into an earlier maximum. */
+/* max |x| over an fp32 [R, C] tensor (row pitch ldx elements) into a device RECORD of 64 floats (256 bytes): each workgroup folds its
+ * maximum into slot (block index & 63) with one atomic max on the bit pattern, consumers take the maximum of the 64 slots.  Every
+ * `amax` argument of this header is such a 64-float record.  zero_first != 0 clears the record first, 0 folds into an earlier one. */
 int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first);
 /* the same for n_segments tensors of one flat buffer in one launch: amax[s] = max |flat[offsets[s] .. offsets[s] + counts[s])|
- * (offsets / counts: device int64 arrays).  Every parameter's scale after an optimizer step. */
+ * (offsets / counts: device int64 arrays; amax: n_segments records of 64 floats).  Every parameter's scale after an optimizer step. */
 int qt_amax_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments, float* amax);
 /* fp32 [R, C] -> split image: per row and per block of 32 columns one 128-byte line [32 x fp16 hi | 32 x fp16 lo] with
  * hi = fp16(s x), lo = fp16(s x - hi); s = 2^e chosen from *amax (nullable: s = 1) so that s * amax lies in [2^13, 2^14).

@@ -114,7 +114,7 @@ SIGNATURES = {
     'qt_amax_f32': [_p, _p, _l, _l, _i, _p, _i],
     'qt_amax_segments': [_p, _p, _p, _p, _i, _p],
     'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
-    'qt_xattn_bwd': [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p],
+    'qt_xattn_bwd': [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
     'qt_attn_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p],
     'qt_attn_causal_fwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _f],
     'qt_text_embed_fwd': [_p, _p, _i, _i, _i, _i, _p, _p, _p],
@@ -125,7 +125,7 @@ SIGNATURES = {
     'qt_cast_f16_f32': [_p, _p, _p, _l],
     'qt_eval_counts': [_p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p],
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
-                    _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],
+                    _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p, _p],
     'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],
     'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
     'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p],

@@ -34,6 +34,7 @@ struct AttnArgs {
     float* dk; long lddk;
     float* dv; long lddv;
     // streaming (long-sequence) path
+    float* g_amax;           // backward, nullable: max|dq,dk,dv| record (64 floats): the in-projection's dY scale, measured while it is written
     float* lse;              // [n_items, H, Lq]  log-sum-exp of the scaled scores (written by fwd, read by bwd)
     const float* o_fwd;      // forward output, same addressing as d_o (bwd: delta = rowsum(dO * O))
     float* delta;            // [n_items, H, Lq] workspace
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
     int first = (kvn - p.kv_shift) % p.n_kv;
     if (first < 0) first += p.n_kv;
     const int reps = p.n_items / p.n_kv;                                // uniform trip count (host guarantees divisibility)
+    float gmax = 0.f;                                                   // max |gradient| this thread writes (g_amax)
     for (int rep = 0; rep < reps; ++rep) {
         const int n = first + rep * p.n_kv;
         __syncthreads();                                                // previous phase B done with Q|dO and PT|ST
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                     if (qo < Lq) {
                         float* drow = p.dq + ((long)n * p.dq_is + (long)qo * p.dq_rs) * p.lddq + hd * DH + c;
 #pragma unroll
-                        for (int dt = 0; dt < DC; ++dt) drow[dt * 16] = oacc[dt][j] * p.scale;
+                        for (int dt = 0; dt < DC; ++dt) { const float dqv = oacc[dt][j] * p.scale; gmax = fmaxf(gmax, fabsf(dqv)); drow[dt * 16] = dqv; }
                     }
                 }
             }
@@ -516,12 +518,17 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                         for (int dt = 0; dt < DC; ++dt) {
                             float kk = ak[dt][j], vv = av[dt][j];
                             if (rep > 0) { kk += dkp[dt * 16]; vv += dvp[dt * 16]; }
+                            gmax = fmaxf(gmax, fmaxf(fabsf(kk), fabsf(vv)));
                             dkp[dt * 16] = kk; dvp[dt * 16] = vv;
                         }
                     }
                 }
             }
         }
+    }
+    if (p.g_amax) {
+        __shared__ float red[4];
+        qt_amax_fold(gmax, red, p.g_amax);
     }
 }
 
@@ -1037,7 +1044,7 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
                            float* dk, long lddk, float* dv, long lddv,
                            int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
                            float scale, float drop_p, unsigned long long seed,
-                           const float* o_fwd, const float* lse, float* delta_ws) {
+                           const float* o_fwd, const float* lse, float* delta_ws, float* g_amax) {
     QT_CHECK_ARG(q && k && v && d_o && dq && dk && dv, "qt_attn_bwd: null pointer");
     QT_CHECK_ARG(n_items > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dh > 0, "qt_attn_bwd: bad sizes");
     QT_CHECK_ARG(n_kv <= n_items, "qt_attn_bwd: n_kv=%d > n_items=%d leaves kv rows without a gradient", n_kv, n_items);
@@ -1048,13 +1055,19 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
     a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
     a.o_fwd = o_fwd; a.lse = (float*)lse; a.delta = delta_ws;
+    a.g_amax = nullptr;
     // the family the FORWARD took for this geometry (attn_path); a backward whose extra conditions fail falls to the
     // generic kernel, which recomputes the softmax itself and needs no log-sum-exp, never to another family
     const int path = attn_path(a, lse != nullptr);
     if (path == QT_ATTN_MFMA && attn_bwd_extras_ok(a, false)) {
         int rc;
+        if (g_amax) {                                   // only this family measures max|dq,dk,dv| while writing them: return 1 = recorded
+            hipError_t e = qt_zero_1d(g_amax, QT_AMAX_SLOTS, (hipStream_t)stream);
+            if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_attn_bwd: zeroing: %s", hipGetErrorString(e));
+            a.g_amax = g_amax;
+        }
         QT_ATTN_DISPATCH(launch_bwd_mfma, a, (hipStream_t)stream, rc);
-        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(mfma)"); return QT_OK; }
+        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(mfma)"); return g_amax ? 1 : QT_OK; }
         QT_FAIL(QT_ERR_RUNTIME, "qt_attn_bwd: MFMA kernel refused Lq=%d Lk=%d d_h=%d (rc %d)", Lq, Lk, dh, rc);
     }
     if (path == QT_ATTN_STREAM && attn_bwd_extras_ok(a, true)) {

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void qt_gemm_f32_kernel(GemmArgs p) {
                     continue;
                 }
                 if (p.add_src) v += p.add_src[(long)m * p.ld_add + n];
-                if (p.relu == 1) v = fmaxf(v, 0.f);
+                if (p.relu == 1) v = qt_relu(v);
                 else if (p.relu == 2) v = v / (1.0f + __expf(-1.702f * v));   // QuickGELU (CLIP text tower MLP)
                 if (p.mask_src) v = (p.mask_src[(long)m * p.ld_mask + n] > 0.f) ? v * p.mask_scale : 0.f;
                 if (p.drop_p > 0.f) v *= qt_drop_mult(p.drop_seed, (unsigned long long)m * (unsigned long long)p.N + n, p.drop_p, p.inv_keep);

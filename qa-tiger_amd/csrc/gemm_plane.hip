@@ -297,6 +297,10 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         });
     };
 
+    // 1 / (s_a s_b) from the operands' max|x| records, read once (all 64 lanes active here)
+    float scale_ab = 1.0f;
+    if (p.a_amax) { const float am = qt_amax_read(p.a_amax); scale_ab *= (FMT == 1 ? qt_fp8_scale(am) : qt_plane_scale(am)); }
+    if (p.b_amax) { const float am = qt_amax_read(p.b_amax); scale_ab *= (FMT == 1 ? qt_fp8_scale(am) : qt_plane_scale(am)); }
     long w = slot;
     if (w >= total) return;
     decode(w);
@@ -365,8 +369,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         if ((p.debug & 1) && acc[0][0][0] != 12345.678f) { if (!more) break; continue; }
         // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
         float alpha = p.alpha;
-        if (p.a_amax) alpha /= (FMT == 1 ? qt_fp8_scale(*p.a_amax) : qt_plane_scale(*p.a_amax));
-        if (p.b_amax) alpha /= (FMT == 1 ? qt_fp8_scale(*p.b_amax) : qt_plane_scale(*p.b_amax));
+        alpha /= scale_ab;
         const int mrow0 = em0 + wm * (WMT * 32) + 4 * h;
         const int ncol0 = en0 + wn * (WNT * 32) + r;
         float bias_v[WNT];
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
                                     float v = alpha * acc[i][j][e] + bias_v[j];
                                     if (has_add) v += addv[e8][j];
                                     if (atomic) { atomicAdd(crow + j * 32, v); return; }
-                                    if (act == 1) v = fmaxf(v, 0.f);
+                                    if (act == 1) v = qt_relu(v);
                                     else if (act == 2) v = v / (1.0f + __expf(-1.702f * v));
                                     if constexpr (full) {
                                         if (p.mask_src) v = (mskv[e8][j] > 0.f) ? v * p.mask_scale : 0.f;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
                         if (has_add) { v[0] += addv[g].x; v[1] += addv[g].y; v[2] += addv[g].z; v[3] += addv[g].w; }
                         if (act == 1) {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                            for (int c = 0; c < 4; ++c) v[c] = qt_relu(v[c]);
                         } else if (act == 2) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[c] = v[c] / (1.0f + __expf(-1.702f * v[c]));
@@ -519,7 +522,7 @@ __device__ inline void qt_split8(const float4& a, const float4& b, float s, uint
 // grid-stride over (row, group of 8 columns); consecutive lanes take consecutive groups: 32-byte reads, 16-byte writes, whole lines per 4 lanes
 __global__ __launch_bounds__(256) void qt_split_f16_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
                                                            char* __restrict__ img, long ld_img) {
-    const float s = amax ? qt_plane_scale(*amax) : 1.0f;
+    const float s = amax ? qt_plane_scale(qt_amax_read(amax)) : 1.0f;
     const int g8 = C >> 3;
     const long total = R * g8;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(256) void qt_split_f16_kernel(const float* __restri
 // so there is no index arithmetic; four independent groups per thread per trip keep 128 B of loads in flight per lane
 __global__ __launch_bounds__(256) void qt_split_f16_flat_kernel(const float* __restrict__ x, long n8, const float* __restrict__ amax,
                                                                 char* __restrict__ img) {
-    const float s = amax ? qt_plane_scale(*amax) : 1.0f;
+    const float s = amax ? qt_plane_scale(qt_amax_read(amax)) : 1.0f;
     const long stride = (long)gridDim.x * 256;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     for (; idx + 3 * stride < n8; idx += 4 * stride) {
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(256) void qt_split_f16_flat_kernel(const float* __r
 #define QT_SPC_TY 8
 __global__ __launch_bounds__(256) void qt_split_f16_colsum_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
                                                                   char* __restrict__ img, long ld_img, int rows_per_chunk, float* __restrict__ colsum) {
-    const float s = amax ? qt_plane_scale(*amax) : 1.0f;
+    const float s = amax ? qt_plane_scale(qt_amax_read(amax)) : 1.0f;
     const int tx = threadIdx.x & (QT_SPC_TX - 1), ty = threadIdx.x / QT_SPC_TX;
     const int c8 = blockIdx.x * QT_SPC_TX + tx;
     const bool on = c8 * 8 < C;
@@ -642,8 +645,8 @@ __global__ __launch_bounds__(256) void qt_amax_kernel(const float* __restrict__ 
         const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
     }
-    m = qt_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
+    __shared__ float red[4];
+    qt_amax_fold(m, red, amax);
 }
 // dense rows: one flat run of float4s, eight independent loads per thread per trip
 __global__ __launch_bounds__(256) void qt_amax_flat_kernel(const float* __restrict__ x, long n4, float* __restrict__ amax) {
@@ -664,8 +667,8 @@ __global__ __launch_bounds__(256) void qt_amax_flat_kernel(const float* __restri
         const float4 a = reinterpret_cast<const float4*>(x)[idx];
         m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
     }
-    const float m = qt_wave_max(fmaxf(m0, m1));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
+    __shared__ float red[4];
+    qt_amax_fold(fmaxf(m0, m1), red, amax);
 }
 
 static __global__ void qt_zero_n_kernel(float* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0.f; }
@@ -679,15 +682,15 @@ __global__ __launch_bounds__(256) void qt_amax_segments_kernel(const float* __re
     const long n = cnt[sgm];
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-    m = qt_wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax + sgm), __builtin_bit_cast(unsigned, m));
+    __shared__ float red[4];
+    qt_amax_fold(m, red, amax + (long)sgm * QT_AMAX_SLOTS);
 }
 
 extern "C" int qt_amax_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments, float* amax) {
     QT_CHECK_ARG(flat && offsets && counts && amax && n_segments > 0, "qt_amax_segments: bad arguments");
     QT_CHECK_ARG(n_segments <= 65535, "qt_amax_segments: too many segments");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = qt_zero_1d(amax, n_segments, st);
+    hipError_t e = qt_zero_1d(amax, (long)n_segments * QT_AMAX_SLOTS, st);
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_amax_segments: zeroing: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(qt_amax_segments_kernel, dim3(8, (unsigned)n_segments), dim3(256), 0, st, flat, offsets, counts, amax);
     QT_CHECK_LAUNCH("qt_amax_segments");
@@ -702,14 +705,14 @@ __global__ __launch_bounds__(256) void qt_amax_scalar_kernel(const float* __rest
         const long row = idx / C;
         m = fmaxf(m, fabsf(x[row * ldx + (idx - row * C)]));
     }
-    m = qt_wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __builtin_bit_cast(unsigned, m));
+    __shared__ float red[4];
+    qt_amax_fold(m, red, amax);
 }
 
 extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first) {
     QT_CHECK_ARG(x && amax && R > 0 && C > 0 && ldx >= C, "qt_amax_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (zero_first) hipLaunchKernelGGL(qt_zero_n_kernel, dim3(1), dim3(64), 0, st, amax, 1);
+    if (zero_first) hipLaunchKernelGGL(qt_zero_n_kernel, dim3(1), dim3(64), 0, st, amax, QT_AMAX_SLOTS);
     if (!(C % 4 == 0 && ldx % 4 == 0 && qt_aligned16(x))) {
         long blocks = (R * C + 255) / 256;
         if (blocks > 1024) blocks = 1024;
@@ -719,7 +722,7 @@ extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C
     }
     const long n4 = R * (C >> 2);
     long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     if (ldx == C) hipLaunchKernelGGL(qt_amax_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n4, amax);
     else hipLaunchKernelGGL(qt_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, R, C, amax);
@@ -875,7 +878,7 @@ extern "C" int qt_gemm_f8(void* stream, int M, int N, int K, float alpha,
 // fp32 [R, C] -> e4m3 image [R][C bytes] (row pitch ld_img bytes), x * 2^e with 2^e * amax in [128, 256); C a multiple of 16.
 __global__ __launch_bounds__(256) void qt_quant_fp8_kernel(const float* __restrict__ x, long ldx, long R, int C, const float* __restrict__ amax,
                                                            char* __restrict__ img, long ld_img) {
-    const float s = amax ? qt_fp8_scale(*amax) : 1.0f;
+    const float s = amax ? qt_fp8_scale(qt_amax_read(amax)) : 1.0f;
     const int g16 = C >> 4;
     const long total = R * g16;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {

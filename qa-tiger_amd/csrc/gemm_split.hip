@@ -57,7 +57,8 @@ struct GemmArgs {          // identical to gemm.hip
     int batch; long a_bs, b_bs, c_bs;   // batched launch (one problem per attention head): count and element strides
     float* a_colsum;          // transA only: a_colsum[m] += sum_k A[k,m]  (bias gradient riding on the dW GEMM)
     const float* a_amax;      // nullable: device max|A|; A is multiplied by the power of two that puts it in fp16's normal range before its split
-    const float* b_amax;      // the same for B (products whose gradient operand is B: dV = P^T dO, dW_k = q^T dU)
+    const float* b_amax;      // the same for B
+    float* c_amax;            // nullable: max|C| record (64 floats) of the values this launch writes (non-split-K launches): the next layer's dY scale (products whose gradient operand is B: dV = P^T dO, dW_k = q^T dU)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     };
     // sA: the gradient operand's power-of-two scale (1 when the operand is taken as it is).  Backward GEMMs hand in max|dY|
     // (a_amax): dY * sA sits in fp16's normal range whatever its magnitude, so the fp16 parts keep 11 + 11 bits there too.
-    const float sA = p.a_amax ? qt_plane_scale(*p.a_amax) : 1.0f;
-    const float sB = p.b_amax ? qt_plane_scale(*p.b_amax) : 1.0f;
+    const float sA = p.a_amax ? qt_plane_scale(qt_amax_read(p.a_amax)) : 1.0f;     // (all lanes active here)
+    const float sB = p.b_amax ? qt_plane_scale(qt_amax_read(p.b_amax)) : 1.0f;
     auto store_kc = [&](u16* hi_img, u16* lo_img, const auto& src, float sc) {
         constexpr int L = sizeof(src) / sizeof(src[0]) / 4;
 #pragma unroll
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         }
     };
     float csum = 0.f;                                               // this thread's share of a_colsum (TA only)
+    float cmax = 0.f;                                               // max |C| written by this thread over all its tiles (c_amax)
     bool do_csum = false;
     auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src, float sc) {
         constexpr int KN = sizeof(src) / sizeof(src[0]);
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                                 float v = alpha_s * acc[i][j][e] + bias_v[j];
                                 if (has_add) v += addv[e8][j];
                                 if (atomic) { atomicAdd(crow + j * 32, v); return; }
-                                if (act == 1) v = fmaxf(v, 0.f);
+                                if (act == 1) v = qt_relu(v);
                                 else if (act == 2) v = v / (1.0f + __expf(-1.702f * v));
                                 if constexpr (full) {
                                     if (p.mask_src) v = (mskv[e8][j] > 0.f) ? v * p.mask_scale : 0.f;
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                                         v *= qt_drop_mult(p.drop_seed, (unsigned long long)m * (unsigned long long)p.N + (ncol0 + j * 32), p.drop_p, p.inv_keep);
                                     v += oldv[e8][j];
                                 }
+                                cmax = fmaxf(cmax, fabsf(v));
                                 crow[j * 32] = v;
                             }
                         });
@@ -455,6 +458,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     } else if (p.add_src) epilogue(std::true_type{}, std::false_type{});
     else epilogue(std::false_type{}, std::false_type{});
         if (!PERSIST || !more) break;
+    }
+    if (p.c_amax) {                                                 // one atomic per wave, spread over the record's 64 slots
+        cmax = qt_wave_max(cmax);
+        if (lane == 0 && (cmax > 0.f || cmax != cmax))
+            atomicMax(reinterpret_cast<unsigned*>(p.c_amax) + ((blockIdx.x + blockIdx.y + blockIdx.z) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, cmax));
     }
 }
 
@@ -508,7 +516,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
                           const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
-                          int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax) {
+                          int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax, float* c_amax) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_x3: bad problem");
     QT_CHECK_ARG(!a_colsum || transA, "qt_gemm_x3: a_colsum needs transA (A given as [K,M])");
     if (batch < 1) batch = 1;
@@ -538,7 +546,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
-    a.a_colsum = a_colsum; a.a_amax = a_amax; a.b_amax = b_amax; a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
+    a.a_colsum = a_colsum; a.a_amax = a_amax; a.b_amax = b_amax; a.c_amax = c_amax; a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");
 
@@ -589,6 +597,11 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
             hipError_t e = qt_zero_2d(C + (long)z * c_bs, ldc, M, N, st);
             if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
         }
+    }
+    if (c_amax) {
+        if (split_k > 1) QT_FAIL(QT_ERR_ARG, "qt_gemm_x3: c_amax needs a non-split-K launch (split_k=%d): partial sums are not the values of C", split_k);
+        hipError_t e = qt_zero_1d(c_amax, QT_AMAX_SLOTS, st);
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: zeroing: %s", hipGetErrorString(e));
     }
     if (a_colsum) {
         hipError_t e = qt_zero_1d(a_colsum, M, st);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void qt_add_ln_fwd_kernel(LnArgs p) {
                 const float4 b = *reinterpret_cast<const float4*>(p.beta + c4 * 4);
                 float4 xh = make_float4(v[t].x * rstd, v[t].y * rstd, v[t].z * rstd, v[t].w * rstd);
                 float4 o = make_float4(fmaf(xh.x, g.x, b.x), fmaf(xh.y, g.y, b.y), fmaf(xh.z, g.z, b.z), fmaf(xh.w, g.w, b.w));
-                if (p.relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                if (p.relu_out) { o.x = qt_relu(o.x); o.y = qt_relu(o.y); o.z = qt_relu(o.z); o.w = qt_relu(o.w); }
                 *reinterpret_cast<float4*>(p.y + (long)row * p.ldy + c4 * 4) = o;
                 if (p.xhat) *reinterpret_cast<float4*>(p.xhat + (long)row * p.D + c4 * 4) = xh;
             }

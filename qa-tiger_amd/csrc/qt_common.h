@@ -50,6 +50,9 @@ __host__ __device__ inline float qt_drop_mult(uint64_t seed, uint64_t idx, float
     return u >= p ? inv_keep : 0.0f;
 }
 
+// ReLU that lets NaN through, as torch.relu does (fmaxf(NaN, 0) is 0: an overflow upstream would turn into plausible finite numbers)
+__device__ inline float qt_relu(float v) { return v < 0.f ? 0.f : v; }
+
 // ---- wave reductions (64 lanes) ---------------------------------------------
 __device__ inline float qt_wave_sum(float v) {
 #pragma unroll
@@ -63,6 +66,27 @@ __device__ inline float qt_wave_max(float v) {
 }
 
 static inline bool qt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- device max|x| records ---------------------------------------------------------------------------------------
+// A tensor's max |x| lives in QT_AMAX_SLOTS floats (256 B): producers fold their block maximum into slot (block index & 63) with
+// one atomicMax on the bit pattern (non-negative floats order like unsigned integers), so a launch of 100k workgroups does not
+// serialise on one address; consumers take the maximum of the 64 slots (one load per lane + a wave reduction).
+#define QT_AMAX_SLOTS 64
+__device__ inline float qt_amax_read(const float* amax) {             // call with all 64 lanes of the wave active
+    return qt_wave_max(amax[threadIdx.x & (QT_AMAX_SLOTS - 1)]);
+}
+// block-level: every thread's value -> one atomicMax per workgroup.  `red` = at least (blockDim.x / 64) floats of LDS.
+__device__ inline void qt_amax_fold(float v, float* red, float* amax) {
+    v = qt_wave_max(v);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+        if (m > 0.f || m != m) atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, m));
+    }
+}
 
 // ---- per-tensor power-of-two scales of 16-bit / 8-bit operand parts -------------------------------------------
 // fp16 (hi, lo) parts: 2^e * amax lands in [2^13, 2^14) — a factor 4 under fp16's largest finite value (65504) for the rounding

@@ -30,6 +30,7 @@ struct XAttnArgs {
     // backward
     const float* dctx; const float* dasum; const float* ctx_in;
     float* du; float* dx;
+    float* dx_amax;          // nullable: max|dx| record (64 floats), measured while dx is written (the out-projection's dY scale)
 };
 
 __device__ inline float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
 // registers — with the dX rows kept in registers in between: 75 KiB, two workgroups per CU.
 template <int NV>
 __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
+    float xmax = 0.f;                                               // max |dx| written by this thread (dx_amax)
     constexpr int QB = 2, GQ = 16;        // (query, head) vectors per pass
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
         }
         __syncthreads();                                            // Ad / Ds / Us / Gs of this pass complete
         const int nq = min(GQ, NQ - grp * GQ);
-        auto store_row = [&](int r, const float4 (&dx)[NV]) {
+        auto store_row = [&](int r, const float4 (&dx)[NV]) {      // (the only place dx is written: max|dx| is taken here)
 #pragma unroll
             for (int t = 0; t < NV; ++t) {
                 const int c4 = lane + t * 64;
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
                     float4* dst = reinterpret_cast<float4*>(p.dx + ((long)n * Lk + r) * D + c4 * 4);
                     float4 v = dx[t];
                     if (grp > 0) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                     *dst = v;
                 }
             }
@@ -346,6 +349,11 @@ __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
                 if (wave + 8 * k < Lk) store_row(wave + 8 * k, dx[k]);
         }
     }
+    if (p.dx_amax) {
+        xmax = qt_wave_max(xmax);
+        if ((threadIdx.x & 63) == 0 && (xmax > 0.f || xmax != xmax))
+            atomicMax(reinterpret_cast<unsigned*>(p.dx_amax) + ((blockIdx.x + (threadIdx.x >> 6)) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, xmax));
+    }
 }
 
 static int xattn_check(const char* who, int n_items, int H, int Lq, int Lk, int D) {
@@ -379,7 +387,7 @@ extern "C" int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, 
 extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
                             const float* ctx, const float* lse, const float* asum, const float* dctx, const float* dasum,
                             int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
-                            float* du, float* dx) {
+                            float* du, float* dx, float* dx_amax) {
     if (int rc = xattn_check("qt_xattn_bwd", n_items, H, Lq, Lk, D)) return rc;
     QT_CHECK_ARG(u && x && ctx && lse && asum && dctx && du && dx, "qt_xattn_bwd: null pointer");
     QT_CHECK_ARG(qt_aligned16(u) && qt_aligned16(x) && qt_aligned16(ctx) && qt_aligned16(dctx) && qt_aligned16(du) && qt_aligned16(dx),
@@ -387,7 +395,11 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     XAttnArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.x = x; a.ctx_in = ctx; a.lse = (float*)lse; a.asum = (float*)asum; a.dctx = dctx; a.dasum = dasum;
     a.u_is = u_is; a.u_rs = u_rs; a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.du = du; a.dx = dx;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.du = du; a.dx = dx; a.dx_amax = dx_amax;
+    if (dx_amax) {
+        hipError_t e = qt_zero_1d(dx_amax, QT_AMAX_SLOTS, (hipStream_t)stream);
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_xattn_bwd: zeroing: %s", hipGetErrorString(e));
+    }
     const int NQ = Lq * H;
     a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
     size_t lds = 0;

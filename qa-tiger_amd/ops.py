@@ -159,7 +159,7 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
          mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
          accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, mode: str = 'fp32',
          a_colsum: Optional[Tensor] = None, batch: Optional[Tuple[int, int, int, int]] = None,
-         a_amax: Optional[Tensor] = None, b_amax: Optional[Tensor] = None) -> Tensor:
+         a_amax: Optional[Tensor] = None, b_amax: Optional[Tensor] = None, c_amax: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)); see include/qatiger.h qt_gemm_f32 / qt_gemm_x3.
     a_amax / b_amax (split modes only): device max|a| / max|b|; that operand is scaled into fp16's normal range before its split (gradient operands)."""
     a, b = as2d(a), as2d(b)
@@ -191,13 +191,14 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     btail = (int(nb), int(a_bs), int(b_bs), int(c_bs))
     if mode != 'fp32':
         rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), mode) + ((nb,) if nb > 1 else ()),
-                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail, _ptr(a_amax), _ptr(b_amax)))
+                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail, _ptr(a_amax), _ptr(b_amax), _ptr(c_amax)))
         if rc == 0:
             return out
         if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
             _lib.check(rc, 'qt_gemm_x3')
         if timer is not None:
             timer.records.pop()
+
     rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), 'fp32') + ((nb,) if nb > 1 else ()), lambda: _lib.load().qt_gemm_f32(
         _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
         _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
@@ -207,6 +208,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     _lib.check(rc, 'qt_gemm_f32')
     if a_colsum is not None:                           # the fp32 kernel has no fused column sum
         _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), 0), 'qt_colsum')
+    if c_amax is not None:                             # ... and does not measure max|C|: one explicit pass into the caller's record
+        _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1), 'qt_amax_f32')
     return out
 
 
@@ -223,13 +226,16 @@ class SplitImage:
         self.data, self.rows, self.cols, self.amax = data, rows, cols, amax
 
 
+AMAX_SLOTS = 64          # a max|x| record is 64 floats; its value is their maximum (csrc/qt_common.h QT_AMAX_SLOTS)
+
+
 def amax_of(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """max |x| as a device float (no host sync); `out` folds into an earlier maximum."""
+    """max |x| as a device record of 64 floats (no host sync; take `.max()` to read it); `out` folds into an earlier one."""
     x = as2d(x)
     _dev(x)
     fresh = out is None
     if fresh:
-        out = torch.empty((1,), device=x.device, dtype=torch.float32)
+        out = torch.empty((AMAX_SLOTS,), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), int(fresh)), 'qt_amax_f32')
     return out
 
@@ -378,10 +384,11 @@ class GradLink:
     `linear(x, W_in, b_in, link=L)` (the block's first layer, whose backward runs later) accumulates its dX GEMM into
     that buffer and hands autograd no gradient of its own — instead of autograd adding two [rows, D] tensors
     (0.32 ms per step on the 660 MB patch activations)."""
-    __slots__ = ('buf',)
+    __slots__ = ('buf', 'res')
 
     def __init__(self):
         self.buf = None
+        self.res = None          # the tensor object autograd carries to the residual's producer: the accumulating dX GEMM tags it with max|sum|
 
 
 def _plane_ok(rows: int, n_out: int, k_in: int) -> bool:
@@ -494,6 +501,11 @@ def act_amax(x: Tensor, x2: Tensor) -> Optional[Tensor]:
     return am
 
 
+def new_amax(device) -> Tensor:
+    """An (uninitialised) max|x| record; the kernel that fills it zeroes it first."""
+    return torch.empty((AMAX_SLOTS,), device=device, dtype=torch.float32)
+
+
 def grad_amax(dy: Tensor, g2: Optional[Tensor] = None) -> Optional[Tensor]:
     """Device max|dY| for the scaled fp16 split of a backward GEMM's gradient operand (None in the modes that do not need it).
     A producer that has already measured it tags the tensor (`dy._qt_amax`); otherwise one streaming pass (qt_amax_f32)."""
@@ -584,8 +596,12 @@ class LinearFn(torch.autograd.Function):
             gam = grad_amax(dy, g)                          # max|dY|: the gradient operand's scale for both GEMMs
             if ctx.needs_input_grad[0]:
                 if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], weight.shape[1]):
-                    gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True, a_amax=gam, b_amax=ctx.wam)   # dx stays None
-                    link.buf = None
+                    # dx stays None; the sum's max|.| is measured by the epilogue that writes it and rides on the residual gradient
+                    cam = new_amax(g.device) if gam is not None else None
+                    gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True, a_amax=gam, b_amax=ctx.wam, c_amax=cam)
+                    if cam is not None and link.res is not None:
+                        link.res._qt_amax = cam
+                    link.buf = link.res = None
                 else:
                     dx = gemm(g, weight, trans_b=False, mode=precision['bwd'], a_amax=gam, b_amax=ctx.wam).reshape(shape)
             if ctx.needs_input_grad[1]:
@@ -603,6 +619,7 @@ class LinearFn(torch.autograd.Function):
                 raise _lib.QTError('residual with relu/dropout epilogue is not differentiable here')
             if link is not None and g.dim() == 2 and g.stride(1) == 1:
                 link.buf = g                            # same memory as dres: the linked first layer adds its dX here
+                link.res = dres
         return dx, dw, db, None, None, None, dres, None, None
 
 
@@ -679,6 +696,8 @@ class AttentionFn(torch.autograd.Function):
         dkb = dqb if packed else torch.empty_like(kb, memory_format=torch.contiguous_format)
         f4 = 4
         delta_ws = torch.empty_like(lse)
+        # packed QKV with no foreign columns: ONE gradient tensor leaves this node, so its max can be measured while it is written
+        gam = new_amax(qb.device) if (packed and precision['bwd'] == 'f16x3' and qb.shape[1] == 3 * s.E) else None
         nbytes = 4.0 * s.E * (3 * s.n_items * s.Lq + 4 * s.n_kv * s.Lk)      # q, dO, dq + k, v, dk, dv
         rc = _launch('attn_bwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_bwd(
             _stream(), C.c_void_p(qb.data_ptr() + s.q_col * f4), _ld(qb), s.q_is, s.q_rs,
@@ -689,9 +708,16 @@ class AttentionFn(torch.autograd.Function):
             C.c_void_p(dkb.data_ptr() + s.k_col * f4), _ld(dkb),
             C.c_void_p(dkb.data_ptr() + s.v_col * f4), _ld(dkb),
             s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed),
-            _ptr(o_fwd), _ptr(lse), _ptr(delta_ws)))
+            _ptr(o_fwd), _ptr(lse), _ptr(delta_ws), _ptr(gam)))
+        if rc == 1:                                    # the MFMA kernels measured max|dq,dk,dv| while writing the packed gradient
+            rc = 0
+        else:
+            gam = None
         _lib.check(rc, 'qt_attn_bwd')
-        return dqb.reshape(qshape), (None if packed else dkb.reshape(kvshape)), None, None, None
+        dq_out = dqb.reshape(qshape)
+        if gam is not None:
+            dq_out._qt_amax = gam                      # the in-projection's backward GEMMs scale dY by it (grad_amax)
+        return dq_out, (None if packed else dkb.reshape(kvshape)), None, None, None
 
 
 def attention(qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float = 0.0, seed: int = 0) -> Tensor:
@@ -801,12 +827,16 @@ class FoldAttnFn(torch.autograd.Function):
         dc = as2d(dc.contiguous())
         dasum = None if dasum is None else dasum.contiguous()
         du, dx = torch.empty_like(u2), torch.empty_like(x2)
+        xam = new_amax(x2.device) if precision['bwd'] == 'f16x3' else None
         nbytes = 4.0 * D * (4 * u2.shape[0] * H + 2 * n_items * Lk)
         rc = _launch('attn_bwd', nbytes, ('fold', n_items, Lq, Lk, D), lambda: _lib.load().qt_xattn_bwd(
             _stream(), _ptr(u2), u_is, u_rs, _ptr(x2), _ptr(c), _ptr(lse), _ptr(asum), _ptr(dc), _ptr(dasum),
-            n_items, H, Lq, Lk, D, float(scale), float(drop_p), C.c_ulonglong(seed), _ptr(du), _ptr(dx)))
+            n_items, H, Lq, Lk, D, float(scale), float(drop_p), C.c_ulonglong(seed), _ptr(du), _ptr(dx), _ptr(xam)))
         _lib.check(rc, 'qt_xattn_bwd')
-        return du.reshape(ushape), dx.reshape(xshape), None, None, None, None, None, None, None, None, None
+        dx_out = dx.reshape(xshape)
+        if xam is not None:
+            dx_out._qt_amax = xam                      # max|dx| measured while dx was written: the producer layer's dY scale
+        return du.reshape(ushape), dx_out, None, None, None, None, None, None, None, None, None
 
 
 def folded_attention(q: Tensor, x: Tensor, mha, n_items: int, Lq: int, Lk: int, u_is: int, u_rs: int,

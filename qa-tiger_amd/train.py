@@ -59,14 +59,14 @@ class FlatParams:
                 p.data = view                     # the module now computes from the flat buffer
         self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
         # max|w| of every parameter (the fp16 split of a weight operand is scaled by it): one launch per optimizer step
-        self.amax = torch.zeros(len(self.params), device=dev, dtype=dt)
+        self.amax = torch.zeros((len(self.params), ops.AMAX_SLOTS), device=dev, dtype=dt)
         self._seg_off = torch.tensor(self.offsets, dtype=torch.int64, device=dev)
         self._seg_cnt = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self.amax_epoch = None
         for i, (p, gv) in enumerate(zip(self.params, self.grad_views)):
             p._qt_gv = gv                          # ops.LinearFn writes dW / db straight into the flat gradient buffer
             if dev.type == 'cuda':
-                p._qt_amax_view = self.amax[i:i + 1]
+                p._qt_amax_view = self.amax[i]
                 p._qt_flat = self
 
     def numel(self) -> int:

@@ -314,7 +314,8 @@ def test_range_guard_large_activations_and_tiny_weights(qt, synth, oracle):
     P = synth.make_state_dict(cfg, 713)
     inp = synth.make_inputs(cfg, 713)
     for n in ('audio_proj.proj.weight', 'video_proj.proj.weight', 'patch_proj.proj.weight'):
-        P[n] = P[n] * 1e-3                                  # ~1e-4 .. 1e-5 weights
+        P[n] = P[n] * 1e-5                                  # ~1e-6 weights: features x weights keeps the projected activations O(1),
+                                                            # so the rest of the network stays as well conditioned as in the other tests
     big = {k: (v * 1e5 if k in ('audio', 'video', 'patch') else v) for k, v in inp.items()}
     model = qt.QA_TIGER(**cfg.model_kwargs())
     model.load_state_dict(P, strict=True)
