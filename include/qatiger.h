@@ -27,6 +27,8 @@ extern "C" {
 
 int qt_version(void);
 const char* qt_last_error(void);
+/* p[0..n) = 0 (a kernel, not a runtime memset: every call of this library is an ordinary capturable launch). */
+int qt_zero_f32(void* stream, float* p, long n);
 
 /* C[M,N] = epilogue(alpha * op(A) op(B)).
  * Replaces nn.Linear / packed MHA in- and out-projections: modules.py:33,43
@@ -64,7 +66,8 @@ int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N
                const float* a_amax /* nullable: device max|A| (qt_amax_f32); A is scaled by the power of two that puts it in fp16's normal
                                       range before its split and the result is scaled back: backward GEMMs pass max|dY| here */,
                const float* b_amax /* the same for B */,
-               float* c_amax /* nullable, non-split-K launches: max|C| record of the values written — the next layer's max|dY| for free */);
+               float* c_amax /* nullable: max|C| record of the values written — the next layer's max|dY| for free.  A launch that had to split K
+                                 (partial sums meet in atomics) does not fill it and returns 2 instead of 0: measure C with qt_amax_f32 then */);
 
 /* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
  * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward
@@ -162,7 +165,9 @@ int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, 
 
 /* max |x| over an fp32 [R, C] tensor (row pitch ldx elements) into a device RECORD of 64 floats (256 bytes): each workgroup folds its
  * maximum into slot (block index & 63) with one atomic max on the bit pattern, consumers take the maximum of the 64 slots.  Every
- * `amax` argument of this header is such a 64-float record.  zero_first != 0 clears the record first, 0 folds into an earlier one. */
+ * `amax` argument of this header is such a 64-float record.  zero_first != 0 clears the record first, 0 folds into an earlier one.
+ * Kernels that fill a record as a by-product (qt_gemm_x3 c_amax, qt_attn_bwd g_amax, qt_xattn_bwd dx_amax) expect it ZEROED by the
+ * caller (the host side hands out records from a pool it zeroes half at a time: no per-record launch). */
 int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first);
 /* the same for n_segments tensors of one flat buffer in one launch: amax[s] = max |flat[offsets[s] .. offsets[s] + counts[s])|
  * (offsets / counts: device int64 arrays; amax: n_segments records of 64 floats).  Every parameter's scale after an optimizer step. */

@@ -1062,9 +1062,7 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
     if (path == QT_ATTN_MFMA && attn_bwd_extras_ok(a, false)) {
         int rc;
         if (g_amax) {                                   // only this family measures max|dq,dk,dv| while writing them: return 1 = recorded
-            hipError_t e = qt_zero_1d(g_amax, QT_AMAX_SLOTS, (hipStream_t)stream);
-            if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_attn_bwd: zeroing: %s", hipGetErrorString(e));
-            a.g_amax = g_amax;
+            a.g_amax = g_amax;                          // (a zeroed record from the caller)
         }
         QT_ATTN_DISPATCH(launch_bwd_mfma, a, (hipStream_t)stream, rc);
         if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_bwd(mfma)"); return g_amax ? 1 : QT_OK; }

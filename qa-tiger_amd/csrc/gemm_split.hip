@@ -219,17 +219,20 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     };
     // sA: the gradient operand's power-of-two scale (1 when the operand is taken as it is).  Backward GEMMs hand in max|dY|
     // (a_amax): dY * sA sits in fp16's normal range whatever its magnitude, so the fp16 parts keep 11 + 11 bits there too.
-    const float sA = p.a_amax ? qt_plane_scale(qt_amax_read(p.a_amax)) : 1.0f;     // (all lanes active here)
-    const float sB = p.b_amax ? qt_plane_scale(qt_amax_read(p.b_amax)) : 1.0f;
-    auto store_kc = [&](u16* hi_img, u16* lo_img, const auto& src, float sc) {
+    const float sA = p.a_amax ? qt_plane_scale_if_needed(qt_amax_read(p.a_amax)) : 1.0f;     // (all lanes active here)
+    const float sB = p.b_amax ? qt_plane_scale_if_needed(qt_amax_read(p.b_amax)) : 1.0f;
+    const bool scA = sA != 1.0f, scB = sB != 1.0f;              // wave-uniform: the unscaled stores carry no multiply
+    // `sc`: a float scale, or std::false_type for "none" (no multiply in the code at all)
+    auto mulsc = [](float x, auto sc) { if constexpr (std::is_same<decltype(sc), float>::value) return x * sc; else return x; };
+    auto store_kc = [&](u16* hi_img, u16* lo_img, const auto& src, auto sc) {
         constexpr int L = sizeof(src) / sizeof(src[0]) / 4;
 #pragma unroll
         for (int it = 0; it < L; ++it) {
             const int idx = tid + it * NT;
             const int row = kc_row(idx), kq = idx & 7;
             uint2 vh, vl;
-            split_pair<HT>(src[it * 4 + 0] * sc, src[it * 4 + 1] * sc, vh.x, vl.x);
-            split_pair<HT>(src[it * 4 + 2] * sc, src[it * 4 + 3] * sc, vh.y, vl.y);
+            split_pair<HT>(mulsc(src[it * 4 + 0], sc), mulsc(src[it * 4 + 1], sc), vh.x, vl.x);
+            split_pair<HT>(mulsc(src[it * 4 + 2], sc), mulsc(src[it * 4 + 3], sc), vh.y, vl.y);
             *reinterpret_cast<uint2*>(hi_img + row * SLD + kq * 4) = vh;
             if constexpr (HT < 2) *reinterpret_cast<uint2*>(lo_img + row * SLD + kq * 4) = vl;
         }
@@ -237,16 +240,16 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     float csum = 0.f;                                               // this thread's share of a_colsum (TA only)
     float cmax = 0.f;                                               // max |C| written by this thread over all its tiles (c_amax)
     bool do_csum = false;
-    auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src, float sc) {
+    auto store_ks = [&](u16* hi_img, u16* lo_img, int edge, const auto& src, auto sc) {
         constexpr int KN = sizeof(src) / sizeof(src[0]);
         const int col = tid % edge, kb = (tid / edge) * KN;
 #pragma unroll
         for (int e = 0; e < KN / 8; ++e) {
             uint4 vh, vl;
-            split_pair<HT>(src[e * 8 + 0] * sc, src[e * 8 + 1] * sc, vh.x, vl.x);
-            split_pair<HT>(src[e * 8 + 2] * sc, src[e * 8 + 3] * sc, vh.y, vl.y);
-            split_pair<HT>(src[e * 8 + 4] * sc, src[e * 8 + 5] * sc, vh.z, vl.z);
-            split_pair<HT>(src[e * 8 + 6] * sc, src[e * 8 + 7] * sc, vh.w, vl.w);
+            split_pair<HT>(mulsc(src[e * 8 + 0], sc), mulsc(src[e * 8 + 1], sc), vh.x, vl.x);
+            split_pair<HT>(mulsc(src[e * 8 + 2], sc), mulsc(src[e * 8 + 3], sc), vh.y, vl.y);
+            split_pair<HT>(mulsc(src[e * 8 + 4], sc), mulsc(src[e * 8 + 5], sc), vh.z, vl.z);
+            split_pair<HT>(mulsc(src[e * 8 + 6], sc), mulsc(src[e * 8 + 7], sc), vh.w, vl.w);
             *reinterpret_cast<uint4*>(hi_img + col * SLD + kb + e * 8) = vh;
             if constexpr (HT < 2) *reinterpret_cast<uint4*>(lo_img + col * SLD + kb + e * 8) = vl;
         }
@@ -263,14 +266,15 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
     auto sstore = [&](int buf, const auto& xa, const auto& xb) {
         u16* b0 = smem + buf * STAGE;
         if (TA) {
-            store_ks(b0, b0 + A_IMG, BM, xa, sA);
+            if (scA) store_ks(b0, b0 + A_IMG, BM, xa, sA); else store_ks(b0, b0 + A_IMG, BM, xa, std::false_type{});
             if (do_csum) {                                          // K-tail and out-of-range rows were loaded as zeros
                 constexpr int KN = sizeof(xa) / sizeof(xa[0]);
 #pragma unroll
                 for (int j = 0; j < KN; ++j) csum += xa[j];
             }
-        } else store_kc(b0, b0 + A_IMG, xa, sA);
-        if (TB) store_kc(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, xb, sB); else store_ks(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, BN, xb, sB);
+        } else { if (scA) store_kc(b0, b0 + A_IMG, xa, sA); else store_kc(b0, b0 + A_IMG, xa, std::false_type{}); }
+        if (TB) { if (scB) store_kc(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, xb, sB); else store_kc(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, xb, std::false_type{}); }
+        else { if (scB) store_ks(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, BN, xb, sB); else store_ks(b0 + 2 * A_IMG, b0 + 2 * A_IMG + B_IMG, BN, xb, std::false_type{}); }
     };
     auto compute = [&](int cur) {
         const u16* b0 = smem + cur * STAGE;
@@ -598,10 +602,9 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
             if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
         }
     }
+    bool cmax_skipped = false;
     if (c_amax) {
-        if (split_k > 1) QT_FAIL(QT_ERR_ARG, "qt_gemm_x3: c_amax needs a non-split-K launch (split_k=%d): partial sums are not the values of C", split_k);
-        hipError_t e = qt_zero_1d(c_amax, QT_AMAX_SLOTS, st);
-        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: zeroing: %s", hipGetErrorString(e));
+        if (split_k > 1) { a.c_amax = nullptr; cmax_skipped = true; }     // partial sums are not the values of C: the caller measures it (return 2)
     }
     if (a_colsum) {
         hipError_t e = qt_zero_1d(a_colsum, M, st);
@@ -622,6 +625,6 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         else qt_x3_small_3(a, transA, transB, grid, st);
     }
     QT_CHECK_LAUNCH("qt_gemm_x3");
-    return QT_OK;
+    return cmax_skipped ? 2 : QT_OK;
 }
 #endif  // QT_X3_PART == 0

@@ -12,6 +12,14 @@ thread_local char qt_err_buf[512] = "";
 extern "C" int qt_version(void) { return QT_ABI_VERSION; }
 extern "C" const char* qt_last_error(void) { return qt_err_buf; }
 
+// zero n floats (max|x| record pools, ...): an ordinary kernel, capturable like everything else here
+extern "C" int qt_zero_f32(void* stream, float* p, long n) {
+    QT_CHECK_ARG(p && n > 0, "qt_zero_f32: bad arguments");
+    hipError_t e = qt_zero_1d(p, n, (hipStream_t)stream);
+    if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_zero_f32: %s", hipGetErrorString(e));
+    return QT_OK;
+}
+
 // ---- column sums ---------------------------------------------------------------
 // grid = (ceil(N/256), row_chunks); each thread owns one column of its chunk:
 // consecutive lanes read consecutive columns (coalesced), partials meet in atomics.

@@ -99,6 +99,12 @@ __host__ __device__ inline float qt_plane_scale(float amax) {
     e = e > 126 ? 126 : (e < -126 ? -126 : e);
     return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
 }
+// Operands converted INSIDE a GEMM (gemm_split.hip) pay one multiply per element pair for a scale, so there it is applied only when
+// it buys precision: an operand whose maximum already lies in [2^-6, 2^14] keeps >= 19 of the 22 bits unscaled (weights and
+// activations of ordinary magnitude: scale 1, no multiply); gradients (1e-3 .. 1e-9), tiny weights and huge activations are scaled.
+__host__ __device__ inline float qt_plane_scale_if_needed(float amax) {
+    return (amax >= 0.015625f && amax <= 16384.0f) ? 1.0f : qt_plane_scale(amax);
+}
 // e4m3 images: 2^e * amax lands in [2^7, 2^8) (the format's largest finite value is 448)
 __host__ __device__ inline float qt_fp8_scale(float amax) {
     if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;

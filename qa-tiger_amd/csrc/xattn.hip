@@ -396,10 +396,6 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     a.u = u; a.x = x; a.ctx_in = ctx; a.lse = (float*)lse; a.asum = (float*)asum; a.dctx = dctx; a.dasum = dasum;
     a.u_is = u_is; a.u_rs = u_rs; a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.du = du; a.dx = dx; a.dx_amax = dx_amax;
-    if (dx_amax) {
-        hipError_t e = qt_zero_1d(dx_amax, QT_AMAX_SLOTS, (hipStream_t)stream);
-        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_xattn_bwd: zeroing: %s", hipGetErrorString(e));
-    }
     const int NQ = Lq * H;
     a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
     size_t lds = 0;

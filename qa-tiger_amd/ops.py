@@ -194,6 +194,9 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
                      lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail, _ptr(a_amax), _ptr(b_amax), _ptr(c_amax)))
         if rc == 0:
             return out
+        if rc == 2:                                    # done, but a split-K launch could not measure max|C|: one explicit pass
+            _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1), 'qt_amax_f32')
+            return out
         if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
             _lib.check(rc, 'qt_gemm_x3')
         if timer is not None:
@@ -229,14 +232,42 @@ class SplitImage:
 AMAX_SLOTS = 64          # a max|x| record is 64 floats; its value is their maximum (csrc/qt_common.h QT_AMAX_SLOTS)
 
 
+class _AmaxPool:
+    """Zeroed max|x| records without a launch per record: 2 x 256 records, the half about to be handed out is zeroed by ONE kernel
+    (records of the other half — a backward pass uses a few dozen — stay readable until the cursor comes round again)."""
+    HALF = 256
+
+    def __init__(self):
+        self.buf = None
+        self.cur = 0
+
+    def take(self, device) -> Tensor:
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.buf = torch.empty((2 * self.HALF, AMAX_SLOTS), device=device, dtype=torch.float32)
+            self.cur = 0
+        if self.cur % self.HALF == 0:
+            half = self.buf[self.cur:self.cur + self.HALF]
+            _lib.check(_lib.load().qt_zero_f32(_stream(), _ptr(half), half.numel()), 'qt_zero_f32')
+        rec = self.buf[self.cur]
+        self.cur = (self.cur + 1) % (2 * self.HALF)
+        return rec
+
+
+_amax_pool = _AmaxPool()
+
+
+def new_amax(device) -> Tensor:
+    """A ZEROED max|x| record for a kernel that measures a maximum as a by-product (pooled: see _AmaxPool)."""
+    return _amax_pool.take(device)
+
+
 def amax_of(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """max |x| as a device record of 64 floats (no host sync; take `.max()` to read it); `out` folds into an earlier one."""
     x = as2d(x)
     _dev(x)
-    fresh = out is None
-    if fresh:
-        out = torch.empty((AMAX_SLOTS,), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), int(fresh)), 'qt_amax_f32')
+    if out is None:
+        out = _amax_pool.take(x.device)
+    _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), 0), 'qt_amax_f32')
     return out
 
 
@@ -499,11 +530,6 @@ def act_amax(x: Tensor, x2: Tensor) -> Optional[Tensor]:
     am = amax_of(x2.detach())
     x._qt_xamax = ((x._version, x.data_ptr()), am)
     return am
-
-
-def new_amax(device) -> Tensor:
-    """An (uninitialised) max|x| record; the kernel that fills it zeroes it first."""
-    return torch.empty((AMAX_SLOTS,), device=device, dtype=torch.float32)
 
 
 def grad_amax(dy: Tensor, g2: Optional[Tensor] = None) -> Optional[Tensor]:
@@ -850,9 +876,12 @@ def folded_attention(q: Tensor, x: Tensor, mha, n_items: int, Lq: int, Lk: int, 
     u = HeadExpandFn.apply(q, W[E:2 * E], H)                                    # W_k folded into the query
     c, asum = FoldAttnFn.apply(u, x, n_items, H, Lq, Lk, u_is, u_rs, 1.0 / math.sqrt(dh), drop_p, seed)
     o = HeadContractFn.apply(c, W[2 * E:], H)                                   # W_v after the weighted sum
-    # + b_v,h * sum_p a_h[p]   (sum = 1 unless attention-probability dropout is active)
-    head_of = torch.arange(E, device=q.device) // dh
-    wb = b[2 * E:, None] * (head_of[:, None] == torch.arange(H, device=q.device)[None, :]).to(b.dtype)   # [E, H]
+    # + b_v,h * sum_p a_h[p]   (sum = 1 unless attention-probability dropout is active): wb[e, h] = b_v[e] * [e belongs to head h]
+    sel = getattr(mha, '_qt_head_sel', None)
+    if sel is None or sel.device != q.device or sel.shape != (E, H):      # constant 0/1 selector, built once per module (was an arange +
+        sel = (torch.arange(E, device=q.device)[:, None] // dh == torch.arange(H, device=q.device)[None, :]).to(b.dtype)   # compare per call)
+        mha._qt_head_sel = sel
+    wb = b[2 * E:, None] * sel                                            # [E, H]; differentiable in b_v
     return linear(asum, wb, None, residual=o)
 
 

@@ -519,5 +519,5 @@ def test_gemm_f16x3_scaled_operands_are_fp32_equivalent(ops, sa, sb, ta, tb):
     raw = ops.gemm(a, b, trans_a=ta, trans_b=tb, mode='f16x3')
     e_raw = rel(raw, ref) if bool(torch.isfinite(raw).all()) else float('inf')
     print(f'scales {sa:g} x {sb:g}: scaled f16x3 {e:.2e}, exact fp32 {e32:.2e}, unscaled f16x3 {e_raw:.2e}')
-    assert e < 2e-6 and e < 4 * e32 + 5e-7
+    assert e < 2e-6 and e < 4 * e32 + 1.5e-6       # (an operand whose maximum is already in [2^-6, 2^14] is left unscaled: >= 19 bits)
     assert e_raw > 10 * e
