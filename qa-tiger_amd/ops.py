@@ -31,7 +31,9 @@ if _os.environ.get('QT_GEMM', '').lower() == 'fp32':
 elif _os.environ.get('QT_GEMM', '').lower() == 'bf16x1':
     precision = {'fwd': 'bf16x1', 'bwd': 'bf16x1'}
 else:
-    precision = {'fwd': 'f16x3', 'bwd': 'f16x3'}     # bwd: fp16 parts too, on dY scaled by its max|dY| (LinearFn.backward)
+    # bwd: fp16 parts too, on dY scaled by its max|dY| (fp32-equivalent products in both directions); QT_BWD=bf16x3 selects round 1's
+    # cheaper backward (bf16 parts of the unscaled gradient: ~1.5e-5 per product, ~8 % faster train step)
+    precision = {'fwd': 'f16x3', 'bwd': 'bf16x3' if _os.environ.get('QT_BWD', '').lower() == 'bf16x3' else 'f16x3'}
 # Pre-split operand pipeline (csrc/gemm_plane.hip): Linear layers whose shapes fit run on split images — the input is split once
 # (and reused by every layer that reads it and by the dW GEMM of the backward), weights are split once per optimizer step, the
 # gradient dY is measured (max|dY|), scaled into fp16's normal range and split once for the dX and dW GEMMs: fp32-equivalent
