@@ -53,7 +53,7 @@ int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float
  * on the fly into hi+lo parts (half_type 0: fp16 parts, ~fp32-accurate, operands must be inside
  * fp16 range — forward GEMMs; 1: bf16 parts, ~1.5e-5 relative, full exponent range — backward GEMMs;
  * 3: ONE bf16 product per term, ~4e-3 relative — the reduced-precision mode of BASELINE config 5, never the parity path).
- * a_colsum (nullable, transA only): a_colsum[m] = sum_k A[k,m] — the bias gradient of a Linear layer
+ * a_colsum (nullable, transA only; with accumulate != 0 it is ADDED to, like C): a_colsum[m] = sum_k A[k,m] — the bias gradient of a Linear layer
  * computed while the dW GEMM streams dY (A = dY given as [rows, N_out]).
  * Returns -4 without touching C or a_colsum when the shape or alignment does not fit its tiles;
  * callers then use qt_gemm_f32 (+ qt_colsum). */
@@ -120,7 +120,8 @@ int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
                   const float* dy, long lddy, const float* xhat, const float* rstd, const float* gamma,
                   const float* sx, const int* drop, const unsigned long long* seed, float drop_p,
                   float* const* dx, const long* lddx, const int* dx_acc,
-                  float* dgamma, float* dbeta);
+                  float* dgamma, float* dbeta,
+                  float* const* dx_amax /* nullable; per addend a nullable max|dx_a| record, zeroed by the caller */);
 
 /* TempMoE router / Gaussian weights (modules.py:565-580, 420-471):
  * logits [B,K], gauss_raw [B,2K] (pairs (u_e, v_e)) -> probs [B,K], topk_inds [B,k] int64
@@ -150,7 +151,7 @@ int qt_add_rows(void* stream, const float* a, long lda, int ra, float alpha,
 /* out = g * mask: y given -> (y>0 ? 1/(1-p) : 0)  [backward of dropout(relu(z)) from its output];
  * y null -> the forward dropout multiplier regenerated from (seed, r*N+c). */
 int qt_mask_grad(void* stream, const float* g, long ldg, const float* y, long ldy, float drop_p,
-                 unsigned long long seed, float* out, long ldo, long rows, int N);
+                 unsigned long long seed, float* out, long ldo, long rows, int N, float* amax /* nullable: max|out| record, zeroed by the caller */);
 /* nn.CrossEntropyLoss(mean) and d loss / d logits (train.py:41, trainutils.py:278,286). */
 int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long* label, int B, int A,
                     float* loss_rows, float* loss_mean, float* dlogits, long ldd);

@@ -128,7 +128,7 @@ SIGNATURES = {
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
                     _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p, _p],
     'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],
-    'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
+    'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p],
     'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p],
     'qt_moe_coef_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'qt_moe_treduce_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -136,7 +136,7 @@ SIGNATURES = {
     'qt_moe_router_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p],
     'qt_colsum': [_p, _p, _l, _i, _i, _p, _i],
     'qt_add_rows': [_p, _p, _l, _i, _f, _p, _l, _i, _f, _p, _l, _l, _i],
-    'qt_mask_grad': [_p, _p, _l, _p, _l, _f, _u64, _p, _l, _l, _i],
+    'qt_mask_grad': [_p, _p, _l, _p, _l, _f, _u64, _p, _l, _l, _i, _p],
     'qt_xent_fwd_bwd': [_p, _p, _l, _p, _i, _i, _p, _p, _p, _l],
     'qt_adam_step': [_p, _p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _f],
 }

@@ -606,7 +606,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     if (c_amax) {
         if (split_k > 1) { a.c_amax = nullptr; cmax_skipped = true; }     // partial sums are not the values of C: the caller measures it (return 2)
     }
-    if (a_colsum) {
+    if (a_colsum && !accumulate) {                  // accumulate: C and a_colsum both hold earlier contributions (a pre-zeroed gradient buffer)
         hipError_t e = qt_zero_1d(a_colsum, M, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
     }

@@ -91,26 +91,33 @@ extern "C" int qt_add_rows(void* stream, const float* a, long lda, int ra, float
 // y null  : out = g * dropout_multiplier(seed, r*N + c)   (same index space as the forward epilogue)
 __global__ __launch_bounds__(256) void qt_mask_grad_kernel(const float* __restrict__ g, long ldg, const float* __restrict__ y, long ldy,
                                                            float drop_p, float inv_keep, unsigned long long seed,
-                                                           float* __restrict__ out, long ldo, long rows, int N) {
+                                                           float* __restrict__ out, long ldo, long rows, int N, float* __restrict__ amax) {
     const long total = rows * N;
+    float gm = 0.f;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long r = idx / N; const int c = (int)(idx - r * N);
         float m;
         if (y) m = y[r * ldy + c] > 0.f ? inv_keep : 0.f;
         else   m = qt_drop_mult(seed, (unsigned long long)idx, drop_p, inv_keep);
-        out[r * ldo + c] = g[r * ldg + c] * m;
+        const float v = g[r * ldg + c] * m;
+        gm = fmaxf(gm, fabsf(v));
+        out[r * ldo + c] = v;
+    }
+    if (amax) {                                                     // max|out| record for the layer's backward GEMMs (zeroed by the caller)
+        __shared__ float red[4];
+        qt_amax_fold(gm, red, amax);
     }
 }
 
 extern "C" int qt_mask_grad(void* stream, const float* g, long ldg, const float* y, long ldy, float drop_p,
-                            unsigned long long seed, float* out, long ldo, long rows, int N) {
+                            unsigned long long seed, float* out, long ldo, long rows, int N, float* amax) {
     QT_CHECK_ARG(g && out && rows > 0 && N > 0, "qt_mask_grad: bad arguments");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_mask_grad: drop_p=%f", drop_p);
     QT_CHECK_ARG(y || drop_p > 0.f, "qt_mask_grad: nothing to mask");
     long blocks = (rows * N + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(qt_mask_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       g, ldg, y, ldy, drop_p, 1.0f / (1.0f - drop_p), seed, out, ldo, rows, N);
+                       g, ldg, y, ldy, drop_p, 1.0f / (1.0f - drop_p), seed, out, ldo, rows, N, amax);
     QT_CHECK_LAUNCH("qt_mask_grad");
     return QT_OK;
 }

@@ -24,6 +24,7 @@ struct LnArgs {
     // backward
     const float* dy; long lddy;
     float* dx[LN_MAX_ADD]; long lddx[LN_MAX_ADD]; int dx_acc[LN_MAX_ADD];
+    float* dx_amax[LN_MAX_ADD];          // nullable per addend: max|dx_a| record (the producing Linear layer's dY scale), zeroed by the caller
     float* dgamma; float* dbeta;
 };
 
@@ -98,6 +99,9 @@ __global__ __launch_bounds__(256) void qt_add_ln_bwd_kernel(LnArgs p) {
     float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int t = 0; t < LN_MAXV; ++t) { ag[t] = make_float4(0.f, 0.f, 0.f, 0.f); ab[t] = ag[t]; }
+    float gmx[LN_MAX_ADD];
+#pragma unroll
+    for (int a = 0; a < LN_MAX_ADD; ++a) gmx[a] = 0.f;
     for (int row = wave_global; row < p.rows; row += nwaves) {
         float4 dxh[LN_MAXV], xh[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void qt_add_ln_bwd_kernel(LnArgs p) {
                     float4* dst = reinterpret_cast<float4*>(p.dx[a] + (long)row * p.lddx[a] + c4 * 4);
                     float4 o = make_float4(ds.x * m0, ds.y * mm1, ds.z * mm2, ds.w * mm3);
                     if (p.dx_acc[a]) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                    gmx[a] = fmaxf(fmaxf(gmx[a], fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                     *dst = o;
                 }
             }
@@ -160,6 +165,13 @@ __global__ __launch_bounds__(256) void qt_add_ln_bwd_kernel(LnArgs p) {
     for (int c = threadIdx.x; c < p.D; c += 256) {
         atomicAdd(p.dgamma + c, red[c]);
         atomicAdd(p.dbeta + c, red[p.D + c]);
+    }
+#pragma unroll
+    for (int a = 0; a < LN_MAX_ADD; ++a) {
+        if (p.dx[a] && p.dx_amax[a]) {                              // block-uniform
+            __syncthreads();
+            qt_amax_fold(gmx[a], red, p.dx_amax[a]);
+        }
     }
 }
 
@@ -195,7 +207,7 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
                              const float* dy, long lddy, const float* xhat, const float* rstd, const float* gamma,
                              const float* sx, const int* drop, const unsigned long long* seed, float drop_p,
                              float* const* dx, const long* lddx, const int* dx_acc,
-                             float* dgamma, float* dbeta) {
+                             float* dgamma, float* dbeta, float* const* dx_amax) {
     if (int rc = ln_check("qt_add_ln_bwd", rows, D)) return rc;
     QT_CHECK_ARG(n_add >= 1 && n_add <= LN_MAX_ADD, "qt_add_ln_bwd: n_add=%d", n_add);
     QT_CHECK_ARG(dy && xhat && rstd && gamma && dgamma && dbeta, "qt_add_ln_bwd: null pointer");
@@ -205,12 +217,13 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
     a.dy = dy; a.lddy = lddy; a.xhat = (float*)xhat; a.rstd = (float*)rstd; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
     for (int i = 0; i < n_add; ++i) {
         a.sx[i] = sx[i]; a.drop[i] = (drop[i] && drop_p > 0.f); a.seed[i] = seed[i];
-        a.dx[i] = dx[i]; a.lddx[i] = lddx[i]; a.dx_acc[i] = dx_acc[i];
+        a.dx[i] = dx[i]; a.lddx[i] = lddx[i]; a.dx_acc[i] = dx_acc[i]; a.dx_amax[i] = dx_amax ? dx_amax[i] : nullptr;
         if (dx[i]) QT_CHECK_ARG(qt_aligned16(dx[i]) && lddx[i] % 4 == 0, "qt_add_ln_bwd: dx %d alignment", i);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = qt_zero_1d(dgamma, D, st);
-    if (e == hipSuccess) e = qt_zero_1d(dbeta, D, st);
+    hipError_t e;
+    if (dbeta == dgamma + D) e = qt_zero_1d(dgamma, 2L * D, st);     // one launch when the two live side by side (ops.py allocates them so)
+    else { e = qt_zero_1d(dgamma, D, st); if (e == hipSuccess) e = qt_zero_1d(dbeta, D, st); }
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_add_ln_bwd: memset: %s", hipGetErrorString(e));
     const int blocks = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);   // 2048 x 4 waves: 32 waves per CU
     hipLaunchKernelGGL(qt_add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);

@@ -382,15 +382,19 @@ def add_rows(a: Tensor, b: Tensor, alpha: float = 1.0, beta: float = 1.0, rows: 
     return out
 
 
-def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int) -> Tensor:
+def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int, want_amax: bool = False) -> Tensor:
+    """g * (ReLU / dropout mask); with want_amax the result is tagged with its max|.| record, measured while it is written."""
     g = as2d(g)
     _dev(g, y)
     out = torch.empty_like(g, memory_format=torch.contiguous_format)
     if y is not None:
         y = as2d(y)
+    am = new_amax(g.device) if (want_amax and precision['bwd'] == 'f16x3') else None
     rc = _lib.load().qt_mask_grad(_stream(), _ptr(g), _ld(g), _ptr(y), _ld(y) if y is not None else 0, float(drop_p),
-                                  C.c_ulonglong(seed), _ptr(out), _ld(out), g.shape[0], g.shape[1])
+                                  C.c_ulonglong(seed), _ptr(out), _ld(out), g.shape[0], g.shape[1], _ptr(am))
     _lib.check(rc, 'qt_mask_grad')
+    if am is not None:
+        out._qt_amax = am
     return out
 
 
@@ -401,6 +405,8 @@ def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int) -> Tenso
 # there by the producing GEMM instead of into a temporary that a hook then copies.  Only the FIRST producer of a
 # parameter in a step may do so (a second use of a shared weight would overwrite it); GradSync.begin() clears the set.
 grad_claims = set()
+grads_prezeroed = False     # train.GradSync.begin() zeroes the flat gradient buffer with ONE launch; the first producer of a claimed
+                            # parameter then ACCUMULATES into its slice (no zeroing launch per dW GEMM for split-K / bias column sums)
 
 
 def _claim_grad_view(param: Tensor):
@@ -589,7 +595,7 @@ class LinearFn(torch.autograd.Function):
         relu, drop_p, seed, has_bias, has_res, premasked, shape = ctx.cfg
         g = as2d(dy)
         if (relu or drop_p > 0.0) and not premasked:
-            g = mask_grad(g, y if relu else None, drop_p, seed)
+            g = dy = mask_grad(g, y if relu else None, drop_p, seed, want_amax=True)      # tagged with max|g| for grad_amax below
         dx = dw = db = dres = None
         link = ctx.link
         want_db = has_bias and ctx.needs_input_grad[2]
@@ -633,12 +639,14 @@ class LinearFn(torch.autograd.Function):
                 else:
                     dx = gemm(g, weight, trans_b=False, mode=precision['bwd'], a_amax=gam, b_amax=ctx.wam).reshape(shape)
             if ctx.needs_input_grad[1]:
+                bgv = None
                 if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
                     bgv = _claim_grad_view(b_param)
                     db = bgv[:] if bgv is not None else torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
                 wgv = _claim_grad_view(w_param)
+                inplace = grads_prezeroed and wgv is not None and (db is None or bgv is not None)
                 dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db, a_amax=gam,
-                          out=None if wgv is None else wgv[:])                                   # [N_out, K_in] = g^T x
+                          out=None if wgv is None else wgv[:], accumulate=inplace)                                   # [N_out, K_in] = g^T x
             elif want_db:
                 db = colsum(g)
         if has_res and ctx.needs_input_grad[6]:
@@ -930,8 +938,11 @@ class AddLayerNormFn(torch.autograd.Function):
         rows, D = xhat.shape
         dxs = [torch.empty((rows, D), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[7 + i] else None
                for i in range(n)]
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        dgb = torch.empty((2, D), device=g.device, dtype=torch.float32)      # side by side: zeroed by one launch
+        dgamma, dbeta = dgb[0], dgb[1]
+        # every dx_i is somebody's dY: its max|.| is measured while it is written (the producing layer's backward GEMMs scale by it)
+        ams = [new_amax(g.device) if (d is not None and precision['bwd'] == 'f16x3') else None for d in dxs]
+        AM = (C.c_void_p * n)(*[a.data_ptr() if a is not None else None for a in ams])
         P = (C.c_void_p * n)(*[d.data_ptr() if d is not None else None for d in dxs])
         L = (C.c_long * n)(*[D] * n)
         Acc = (C.c_int * n)(*[0] * n)
@@ -939,9 +950,12 @@ class AddLayerNormFn(torch.autograd.Function):
         Dr = (C.c_int * n)(*[int(d) for d in drops])
         Sd = (C.c_ulonglong * n)(*sds)
         rc = _lib.load().qt_add_ln_bwd(_stream(), rows, D, n, _ptr(g), _ld(g), _ptr(xhat), _ptr(rstd), _ptr(gamma),
-                                       S, Dr, Sd, float(drop_p), P, L, Acc, _ptr(dgamma), _ptr(dbeta))
+                                       S, Dr, Sd, float(drop_p), P, L, Acc, _ptr(dgamma), _ptr(dbeta), AM)
         _lib.check(rc, 'qt_add_ln_bwd')
         outs = [d.reshape(shp) if d is not None else None for d, shp in zip(dxs, shapes)]
+        for o_, a_ in zip(outs, ams):
+            if o_ is not None and a_ is not None:
+                o_._qt_amax = a_
         return (dgamma, dbeta, None, None, None, None, None, *outs)
 
 
@@ -1206,7 +1220,7 @@ class BmmAttentionFn(torch.autograd.Function):
         lib = _lib.load()
         if drop_p > 0.0:
             Y = torch.empty_like(P)
-            _lib.check(lib.qt_mask_grad(_stream(), _ptr(P), Lk, None, 0, float(drop_p), C.c_ulonglong(seed), _ptr(Y), Lk, n_items * Lq, Lk), 'qt_mask_grad')
+            _lib.check(lib.qt_mask_grad(_stream(), _ptr(P), Lk, None, 0, float(drop_p), C.c_ulonglong(seed), _ptr(Y), Lk, n_items * Lq, Lk, None), 'qt_mask_grad')
         else:
             Y = P
         gam_o = grad_amax(dO)                                        # gradient operands are scaled by their max before the fp16 split

@@ -158,7 +158,10 @@ class GradSync:
         self.flat.check()
         for p in self.flat.params:
             p.grad = None
-        ops.grad_claims.clear()                   # first producer of a parameter's gradient this step may write in place
+        ops.grad_claims.clear()
+        if self.flat.grad.is_cuda:                # one launch; claimed dW / db producers accumulate into it (ops.grads_prezeroed)
+            ops._lib.check(ops._lib.load().qt_zero_f32(ops._stream(), ops._ptr(self.flat.grad), self.flat.grad.numel()), 'qt_zero_f32')
+            ops.grads_prezeroed = True                   # first producer of a parameter's gradient this step may write in place
         self._pending = [bk[2] for bk in self.buckets]
         self._seen = [False] * len(self.flat.params)
         self._fired = [False] * len(self.buckets)
@@ -169,9 +172,11 @@ class GradSync:
         zero; flush unfinished buckets; wait for the collectives."""
         if self.trace is not None:
             self.trace.append(('finish',))
-        for i, seen in enumerate(self._seen):
-            if not seen:
-                self.flat.grad_views[i].zero_()
+        if not (self.flat.grad.is_cuda and ops.grads_prezeroed):
+            for i, seen in enumerate(self._seen):
+                if not seen:
+                    self.flat.grad_views[i].zero_()
+        ops.grads_prezeroed = False
         for b, fired in enumerate(self._fired):
             if not fired:
                 self._fire(b)
