@@ -313,19 +313,15 @@ class GraphedForward:
     (valid until the next call).  Every kernel of the library enqueues on torch's current stream without allocating or
     synchronising (include/qatiger.h conventions), so the capture itself needs nothing special.
 
-    ROCm 7.2 caveat, found with tools/graph_probe.py: with the runtime's graph PACKET CAPTURE on (the default), a
-    runtime blit kernel between two replays (any contiguous device-to-device `copy_` / `clone`, any `hipMemsetAsync`)
-    makes the next replay of a graph of this size end in a GPU memory-access fault; single components replay fine, an
-    ATen elementwise kernel in between is harmless, and `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0` removes the fault.  The
-    variable is read when the HIP runtime initialises, so it must be in the environment BEFORE the process first touches
-    the GPU; this class refuses to build otherwise."""
-
-    ENV = 'DEBUG_CLR_GRAPH_PACKET_CAPTURE'
+    Round-1 history: replays of the whole-model graph ended in a GPU memory-access fault whenever a runtime blit ran between
+    two replays, and the class demanded DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.  The cause was in this library: its capturable
+    entry points issued `hipMemsetAsync` (split-K output zeroing, bias-gradient and LayerNorm-gradient accumulators), which
+    become runtime BLIT NODES inside the captured graph — the very class of operation the fault followed.  Every zeroing is
+    now an ordinary kernel of the library (csrc/qt_common.h qt_zero_1d / qt_zero_2d); with that, `tools/graph_probe.py
+    full_clone` replays the whole-model graph with a blit between replays at the runtime's DEFAULT settings
+    (gpurun_out/r2_t14_graph_probe.log), and no environment variable is needed any more."""
 
     def __init__(self, model: nn.Module, example: Dict[str, Tensor], warmup: int = 2):
-        if _os.environ.get(self.ENV) != '0':
-            raise ops._lib.QTError(f'GraphedForward needs {self.ENV}=0 in the environment before the process initialises the GPU '
-                                   '(ROCm 7.2: replays of packet-captured graphs fault after an intervening runtime blit)')
         if model.training:
             raise ValueError('GraphedForward captures the eval forward; call model.eval() first (train-mode dropout seeds '
                              'are host-side kernel arguments and would be frozen into the graph)')
@@ -334,7 +330,7 @@ class GraphedForward:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                     # lazy initialisation (library load, kernel attributes) outside the capture
+            for _ in range(warmup):                     # lazy initialisation (library load, kernel attributes, weight scales) outside the capture
                 model(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()

@@ -435,14 +435,14 @@ def test_bf16x1_gemm(qt, shape):
 
 
 def test_graphed_forward_in_a_fresh_process(qt):
-    """HIP-graph capture of the eval forward (qt.GraphedForward).  It needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 from process
-    start (ROCm 7.2: see the class docstring), so the check runs tools/bench_graph.py in a child process: captured
-    logits equal the eager ones for the captured batch, for another batch, and after an eager forward between replays."""
+    """HIP-graph capture of the eval forward (qt.GraphedForward) at the runtime's DEFAULT settings — round 1 needed
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 because the library's own hipMemsetAsync nodes made replays fault; every zeroing is a kernel
+    now.  The check runs tools/bench_graph.py in a child process WITHOUT that variable: captured logits equal the eager ones for
+    the captured batch, for another batch, and after an eager forward plus runtime blits (memset, copy) between replays."""
     import os, subprocess, sys
     from conftest import REPO
-    with pytest.raises(qt._lib.QTError):
-        qt.GraphedForward(torch.nn.Linear(2, 2).eval(), {})         # this process was not started with the variable
-    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE='0')
-    res = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bench_graph.py'), '8'], cwd=REPO, env=env,
+    env = {k: v for k, v in os.environ.items() if k != 'DEBUG_CLR_GRAPH_PACKET_CAPTURE'}
+    res = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bench_graph.py'), '8', '32'], cwd=REPO, env=env,
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().endswith('OK'), res.stdout[-2000:] + res.stderr[-2000:]
+    print(res.stdout)
