@@ -62,6 +62,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=100.0, help='seconds of CPU work the bounded CPU-baseline sample may take (it picks the largest batch <= 256 that fits)')
     ap.add_argument('--cpu-sample', type=int, default=0, help='force the batch of the CPU-baseline sample (0 = pick by --cpu-budget)')
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto', help='replay the train step from one HIP graph (qt.GraphedTrainStep). auto = when the per-GPU batch is <= 64, where eager steps are host-bound (the 8-GPU strong-scaling shard is B=32)')
     ap.add_argument('--no-strict-fp32', action='store_true', help='skip the exact-fp32 MFMA (QT_GEMM=fp32) comparison line')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
     ap.add_argument('--skip-fwd-only', action='store_true', help='skip the forward-only passes (used by tools/pmc_step_traffic.sh so that every profiled launch belongs to a train step)')
@@ -233,9 +234,14 @@ def main():
             return float(tmax)
         return dt
 
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and per_gpu <= 64)
+    step_fn = (lambda: eng.step(batch))
+    if use_graph:
+        gstep = qt.GraphedTrainStep(eng, batch, warmup=max(2, args.warmup))
+        step_fn = (lambda: gstep(batch))
     for _ in range(args.warmup):
-        eng.step(batch)
-    dt, hip_ms, loss = timed_steps(lambda: eng.step(batch), args.steps, sync)
+        step_fn()
+    dt, hip_ms, loss = timed_steps(step_fn, args.steps, sync)
     dt = max_over_ranks(dt)
     ms_step = dt / args.steps * 1e3
     value = per_gpu * world * args.steps / dt
@@ -488,6 +494,7 @@ def main():
                                    'CLIP/VGGish/ToMe-shaped features, reference initialisers',
                        'per_gpu_batch': per_gpu, 'global_batch': per_gpu * world, 'T': cfg.T, 'D': cfg.D, 'video_dim': cfg.Dv,
                        'audio_dim': cfg.Da, 'patch_dim': cfg.Dp, 'P': cfg.P, 'L': cfg.L, 'experts': cfg.K, 'topK': cfg.k,
+                       'train_step_issue': 'one HIP graph replay per step (qt.GraphedTrainStep)' if use_graph else 'eager launches',
                        'parallelism': f'dp{world}', 'backend': ('rccl' if args.backend == 'nccl' else args.backend) if world > 1 else None},
             'fwd_only': {'value': round(fwd_value, 2), 'unit': 'QA-pairs/s', 'mode': 'eval, no_grad', 'target': 10000, 'hip_event_ms': fwd_hip,
                          'algorithmic_tflops': round(fwd_value * GFLOP_FWD * 1e9 / 1e12 / world, 1)},

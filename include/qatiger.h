@@ -27,6 +27,12 @@ extern "C" {
 
 int qt_version(void);
 const char* qt_last_error(void);
+/* Per-step dropout salt: dropout seeds are call arguments (frozen inside a captured HIP graph), so every dropout-carrying kernel adds the
+ * device word registered here to its seed; bump it once per step (a one-thread kernel, part of the captured step) and every replay draws
+ * fresh masks while the forward and backward of one step still agree.  NULL (default): seeds are used as passed.  This pointer is the one
+ * piece of library-global state. */
+int qt_set_dropout_salt(const unsigned long long* salt_dev);
+int qt_bump_dropout_salt(void* stream, unsigned long long* salt_dev, unsigned long long inc);
 /* p[0..n) = 0 (a kernel, not a runtime memset: every call of this library is an ordinary capturable launch). */
 int qt_zero_f32(void* stream, float* p, long n);
 
@@ -160,6 +166,10 @@ int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long*
  * (torch's L2 form, not AdamW). */
 int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                  int step, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay);
+/* The same with the step count in DEVICE memory (a captured train step cannot take it as an argument): ++step_dev[0], the two bias
+ * corrections go to bc_dev[0..1] (one-thread kernel), then the update reads them. */
+int qt_adam_step_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                     long long* step_dev, float* bc_dev, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay);
 
 /* ---- pre-split operands (csrc/gemm_plane.hip): the same Linear / projection GEMMs and their backward, on operands whose
  * fp32 -> (hi, lo) fp16 split was done ONCE by a producer pass instead of inside every tile of the GEMM. ---- */

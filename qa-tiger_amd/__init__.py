@@ -22,6 +22,6 @@ from .src.models.tspm import TSPM                    # noqa: E402,F401
 from .src.models.modules import (                   # noqa: E402,F401
     Projection, AVQCrossAttn, QstGrounding, TempMoE, PatchSelecter)
 from .src.models.encoders import CLIP_TEncoder      # noqa: E402,F401
-from .train import CrossEntropyLoss, FusedAdam, FlatParams, DataParallelStep, GraphedForward   # noqa: E402,F401
+from .train import CrossEntropyLoss, FusedAdam, FlatParams, DataParallelStep, GraphedForward, GraphedTrainStep   # noqa: E402,F401
 
 __version__ = '0.1.0'

@@ -112,6 +112,9 @@ SIGNATURES = {
     'qt_quant_fp8': [_p, _p, _l, _l, _i, _p, _p, _l],
     'qt_split_f16': [_p, _p, _l, _l, _i, _p, _p, _l, _p],
     'qt_zero_f32': [_p, _p, _l],
+    'qt_set_dropout_salt': [_p],
+    'qt_bump_dropout_salt': [_p, _p, _u64],
+    'qt_adam_step_dev': [_p, _p, _p, _p, _p, _l, _p, _p, _f, _f, _f, _f, _f, _f],
     'qt_amax_f32': [_p, _p, _l, _l, _i, _p, _i],
     'qt_amax_segments': [_p, _p, _p, _p, _i, _p],
     'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],

@@ -27,7 +27,7 @@ struct AttnArgs {
     float* o; long ldo, o_is, o_rs;
     int n_items, n_kv, kv_shift, H, Lq, Lk, dh;
     float scale, drop_p, inv_keep;
-    unsigned long long seed;
+    unsigned long long seed; const unsigned long long* salt;     // salt: qt_common.h "per-step dropout salt"
     // backward only
     const float* d_o; long lddo, do_is, do_rs;
     float* dq; long lddq, dq_is, dq_rs;
@@ -46,6 +46,7 @@ __device__ inline int lds_pad(int dh) { return dh + 1; }   // odd row stride: co
 // Forward: grid = n_items * H, block = NT threads.
 template <int NT>
 __global__ __launch_bounds__(NT) void qt_attn_fwd_kernel(AttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.x / p.H, hd = blockIdx.x - n * p.H;
     const int kvn = (n + p.kv_shift) % p.n_kv;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(NT) void qt_attn_fwd_kernel(AttnArgs p) {
 // head) and walks every query item that attends to it, so dK/dV need no atomics.
 template <int NT>
 __global__ __launch_bounds__(NT) void qt_attn_bwd_kernel(AttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int kvn = blockIdx.x / p.H, hd = blockIdx.x - kvn * p.H;
     const int Lq = p.Lq, Lk = p.Lk, dh = p.dh, dp = lds_pad(dh), sp = Lk + 1;
@@ -229,6 +231,7 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 
 template <int DC, int NKT>
 __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int wpp) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DH = DC * 16, LDK = DH + 4, KR = NKT * 16, V4 = DH / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int w
 
 template <int DC, int NKT>
 __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int wpp, int nqt) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DH = DC * 16, LDK = DH + 4, KR = NKT * 16, V4 = DH / 4;
     const int LDQ = nqt * 16 + 4, QR = nqt * 16;
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
 
 template <int DC>
 __global__ __launch_bounds__(256) void qt_attn_fwd_stream_kernel(AttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DH = DC * 16, LDK = DH + 4, V4 = DH / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -663,6 +668,7 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_stream_kernel(AttnArgs p) {
 // dQ (and delta = rowsum(dO*O)) per 16-query tile; streams K/V chunks.
 template <int DC>
 __global__ __launch_bounds__(256) void qt_attn_bwd_dq_kernel(AttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DH = DC * 16, LDK = DH + 4, V4 = DH / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -765,6 +771,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_dq_kernel(AttnArgs p) {
 // the lane) is directly the A operand of dV = P^T·dO and dK = dS^T·Q.
 template <int DC>
 __global__ __launch_bounds__(256) void qt_attn_bwd_dkv_kernel(AttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DH = DC * 16, LDK = DH + 4, V4 = DH / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -983,7 +990,7 @@ static int attn_fwd_impl(void* stream, const float* q, long ldq, long q_is, long
     a.q = q; a.ldq = ldq; a.q_is = q_is; a.q_rs = q_rs; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.kv_is = kv_is;
     a.o = o; a.ldo = ldo; a.o_is = o_is; a.o_rs = o_rs;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
-    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.lse = lse; a.causal = causal;
+    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr; a.lse = lse; a.causal = causal;
     // causal (text tower, forward only) always streams K/V with an online softmax and needs no log-sum-exp
     int path = attn_path(a, causal || lse != nullptr);
     if (causal && path == QT_ATTN_MFMA) path = QT_ATTN_STREAM;
@@ -1053,7 +1060,7 @@ extern "C" int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, lo
     a.d_o = d_o; a.lddo = lddo; a.do_is = do_is; a.do_rs = do_rs;
     a.dq = dq; a.lddq = lddq; a.dq_is = dq_is; a.dq_rs = dq_rs; a.dk = dk; a.lddk = lddk; a.dv = dv; a.lddv = lddv;
     a.n_items = n_items; a.n_kv = n_kv; a.kv_shift = kv_shift; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = dh;
-    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    a.scale = scale; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr;
     a.o_fwd = o_fwd; a.lse = (float*)lse; a.delta = delta_ws;
     a.g_amax = nullptr;
     // the family the FORWARD took for this geometry (attn_path); a backward whose extra conditions fail falls to the

@@ -39,7 +39,7 @@ struct GemmArgs {
     const float* add_src; long ld_add; // residual added before the activation
     int relu;
     const float* mask_src; long ld_mask; float mask_scale;  // out = mask_src>0 ? out*mask_scale : 0
-    float drop_p; float inv_keep; unsigned long long drop_seed;
+    float drop_p; float inv_keep; unsigned long long drop_seed; const unsigned long long* salt;   // salt: qt_common.h "per-step dropout salt"
     int accumulate;                    // C += out
     int split_k;                       // >1: K split over gridDim.y, atomically added into C
     int k_per_split;                   // multiple of BK
@@ -49,6 +49,7 @@ struct GemmArgs {
 
 template <int TM, int TN, bool TA, bool TB, int VEC>
 __global__ __launch_bounds__(256) void qt_gemm_f32_kernel(GemmArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_TILE = TA ? BK * BM : BM * LDK;
     constexpr int B_TILE = TB ? BN * LDK : BK * BN;
@@ -269,7 +270,7 @@ extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, i
     a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.salt = qt_salt_ptr; a.accumulate = accumulate;
 
     // 16-byte vector staging needs aligned rows; otherwise the scalar-load build of the same kernel
     const bool vecA = qt_aligned16(A) && (lda % 4 == 0) && ((transA ? M : K) % 4 == 0) && (batch == 1 || a_bs % 4 == 0);

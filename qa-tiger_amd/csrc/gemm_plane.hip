@@ -60,7 +60,7 @@ struct PlaneArgs {
     const float* add_src; long ld_add;
     int relu;
     const float* mask_src; long ld_mask; float mask_scale;
-    float drop_p; float inv_keep; unsigned long long drop_seed;
+    float drop_p; float inv_keep; unsigned long long drop_seed; const unsigned long long* salt;   // salt: qt_common.h "per-step dropout salt"
     int accumulate;
     int split_k, k_per_split, tiles_n, tiles_m;
     int debug;                       // QT_PS_DEBUG (profiling probes only): 1 skip the write-out, 2 DMA only for the first step of a tile, 4 no MFMAs
@@ -88,6 +88,7 @@ template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_
 //        schedule: a K step is always one 128-byte line per row.
 template <bool AKS, bool BKS, bool SWAP, int FMT>
 __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
     constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
     constexpr int WMT = 4, WNT = 2, NWN = 4;          // wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32
@@ -787,7 +788,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     a.M = M; a.N = N; a.K = K; a.A = (const char*)A; a.lda = lda_bytes; a.B = (const char*)B; a.ldb = ldb_bytes; a.C = C; a.ldc = ldc;
     a.alpha = alpha; a.a_amax = a_amax; a.b_amax = b_amax; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.salt = qt_salt_ptr; a.accumulate = accumulate;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QT_PS_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "%s: split_k>1 needs a linear epilogue", who);

@@ -48,7 +48,7 @@ struct GemmArgs {          // identical to gemm.hip
     const float* add_src; long ld_add;
     int relu;
     const float* mask_src; long ld_mask; float mask_scale;
-    float drop_p; float inv_keep; unsigned long long drop_seed;
+    float drop_p; float inv_keep; unsigned long long drop_seed; const unsigned long long* salt;   // salt: qt_common.h "per-step dropout salt"
     int accumulate;
     int split_k;
     int k_per_split;
@@ -116,6 +116,7 @@ template <int HT> __device__ inline floatx16 mma(const uint4& a, const uint4& b,
 //                      for the M = B*T*P GEMMs whose grids are large enough to fill 256 single-slot CUs.
 template <int WMT, int WNT, int NWM, int NWN, int PREF, bool TA, bool TB, int HT>
 __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_gemm_x3_kernel(GemmArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     constexpr int NT = NWM * NWN * 64;
     constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32;
     constexpr int A_IMG = BM * SLD, B_IMG = BN * SLD;               // one 16-bit image
@@ -549,7 +550,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
     a.alpha = alpha; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.accumulate = accumulate;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.salt = qt_salt_ptr; a.accumulate = accumulate;
     a.a_colsum = a_colsum; a.a_amax = a_amax; a.b_amax = b_amax; a.c_amax = c_amax; a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "qt_gemm_x3: split_k>1 needs a linear epilogue");

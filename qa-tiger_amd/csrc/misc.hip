@@ -8,9 +8,20 @@
 #include <math.h>
 
 thread_local char qt_err_buf[512] = "";
+const unsigned long long* qt_salt_ptr = nullptr;
 
 extern "C" int qt_version(void) { return QT_ABI_VERSION; }
 extern "C" const char* qt_last_error(void) { return qt_err_buf; }
+
+// ---- dropout salt (see qt_common.h) and the device-side step counter of the captured train step ---------------------
+extern "C" int qt_set_dropout_salt(const unsigned long long* salt_dev) { qt_salt_ptr = salt_dev; return QT_OK; }
+static __global__ void qt_bump_salt_kernel(unsigned long long* salt, unsigned long long inc) { if (threadIdx.x == 0) *salt += inc; }
+extern "C" int qt_bump_dropout_salt(void* stream, unsigned long long* salt_dev, unsigned long long inc) {
+    QT_CHECK_ARG(salt_dev, "qt_bump_dropout_salt: null pointer");
+    hipLaunchKernelGGL(qt_bump_salt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, salt_dev, inc);
+    QT_CHECK_LAUNCH("qt_bump_dropout_salt");
+    return QT_OK;
+}
 
 // zero n floats (max|x| record pools, ...): an ordinary kernel, capturable like everything else here
 extern "C" int qt_zero_f32(void* stream, float* p, long n) {
@@ -91,7 +102,9 @@ extern "C" int qt_add_rows(void* stream, const float* a, long lda, int ra, float
 // y null  : out = g * dropout_multiplier(seed, r*N + c)   (same index space as the forward epilogue)
 __global__ __launch_bounds__(256) void qt_mask_grad_kernel(const float* __restrict__ g, long ldg, const float* __restrict__ y, long ldy,
                                                            float drop_p, float inv_keep, unsigned long long seed,
-                                                           float* __restrict__ out, long ldo, long rows, int N, float* __restrict__ amax) {
+                                                           float* __restrict__ out, long ldo, long rows, int N, float* __restrict__ amax,
+                                                           const unsigned long long* __restrict__ salt) {
+    if (salt) seed += *salt;
     const long total = rows * N;
     float gm = 0.f;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -117,7 +130,7 @@ extern "C" int qt_mask_grad(void* stream, const float* g, long ldg, const float*
     long blocks = (rows * N + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(qt_mask_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       g, ldg, y, ldy, drop_p, 1.0f / (1.0f - drop_p), seed, out, ldo, rows, N, amax);
+                       g, ldg, y, ldy, drop_p, 1.0f / (1.0f - drop_p), seed, out, ldo, rows, N, amax, qt_salt_ptr);
     QT_CHECK_LAUNCH("qt_mask_grad");
     return QT_OK;
 }
@@ -192,6 +205,39 @@ __global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, con
         v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
         p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
     }
+}
+
+// Device-side step count for a CAPTURED train step: step_dev[0] is incremented and the two bias corrections are written to
+// bc_dev[0..1] by a one-thread kernel; the update kernel reads them from memory instead of taking them as (frozen) arguments.
+static __global__ void qt_adam_prep_kernel(long long* step_dev, float* bc_dev, float b1, float b2) {
+    if (threadIdx.x == 0) {
+        const long long t = ++(*step_dev);
+        bc_dev[0] = (float)(1.0 - pow((double)b1, (double)t));
+        bc_dev[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    }
+}
+__global__ __launch_bounds__(256) void qt_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                          const float* __restrict__ bc, float grad_scale, float wd) {
+    const float bc1 = bc[0], bc2_sqrt = bc[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gr = g[i] * grad_scale + wd * p[i];
+        const float mm = b1 * m[i] + (1.f - b1) * gr, vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mm; v[i] = vv;
+        p[i] -= (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    }
+}
+extern "C" int qt_adam_step_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                                long long* step_dev, float* bc_dev, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay) {
+    QT_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev && bc_dev, "qt_adam_step_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(qt_adam_prep_kernel, dim3(1), dim3(64), 0, st, step_dev, bc_dev, beta1, beta2);
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(qt_adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       bc_dev, grad_scale, weight_decay);
+    QT_CHECK_LAUNCH("qt_adam_step_dev");
+    return QT_OK;
 }
 
 extern "C" int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,

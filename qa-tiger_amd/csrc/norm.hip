@@ -16,7 +16,7 @@
 struct LnArgs {
     int rows, D;
     const float* x[LN_MAX_ADD]; long ldx[LN_MAX_ADD]; float sx[LN_MAX_ADD];
-    int drop[LN_MAX_ADD]; unsigned long long seed[LN_MAX_ADD];
+    int drop[LN_MAX_ADD]; unsigned long long seed[LN_MAX_ADD]; const unsigned long long* salt;
     float drop_p, inv_keep, eps;
     const float* gamma; const float* beta;
     float* y; long ldy; int relu_out;
@@ -29,6 +29,11 @@ struct LnArgs {
 };
 
 __global__ __launch_bounds__(256) void qt_add_ln_fwd_kernel(LnArgs p) {
+    if (p.salt && p.drop_p > 0.f) {
+        const unsigned long long sl = *p.salt;
+#pragma unroll
+        for (int a = 0; a < LN_MAX_ADD; ++a) p.seed[a] += sl;
+    }
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -92,6 +97,11 @@ __global__ __launch_bounds__(256) void qt_add_ln_fwd_kernel(LnArgs p) {
 // dgamma/dbeta: each wave accumulates its rows in registers, then one atomicAdd
 // per column per wave (dgamma/dbeta are zeroed by the launcher).
 __global__ __launch_bounds__(256) void qt_add_ln_bwd_kernel(LnArgs p) {
+    if (p.salt && p.drop_p > 0.f) {
+        const unsigned long long sl = *p.salt;
+#pragma unroll
+        for (int a = 0; a < LN_MAX_ADD; ++a) p.seed[a] += sl;
+    }
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -190,7 +200,7 @@ extern "C" int qt_add_ln_fwd(void* stream, int rows, int D, int n_add,
     QT_CHECK_ARG(n_add >= 1 && n_add <= LN_MAX_ADD, "qt_add_ln_fwd: n_add=%d", n_add);
     QT_CHECK_ARG(gamma && beta && y, "qt_add_ln_fwd: null pointer");
     LnArgs a; memset(&a, 0, sizeof(a));
-    a.rows = rows; a.D = D; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.eps = eps;
+    a.rows = rows; a.D = D; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.eps = eps; a.salt = qt_salt_ptr;
     for (int i = 0; i < n_add; ++i) {
         QT_CHECK_ARG(x[i] && qt_aligned16(x[i]) && ldx[i] % 4 == 0, "qt_add_ln_fwd: addend %d must be 16-byte aligned with ld%%4==0", i);
         a.x[i] = x[i]; a.ldx[i] = ldx[i]; a.sx[i] = sx[i]; a.drop[i] = (drop[i] && drop_p > 0.f); a.seed[i] = seed[i];
@@ -213,7 +223,7 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
     QT_CHECK_ARG(dy && xhat && rstd && gamma && dgamma && dbeta, "qt_add_ln_bwd: null pointer");
     QT_CHECK_ARG(qt_aligned16(dy) && lddy % 4 == 0, "qt_add_ln_bwd: dy alignment");
     LnArgs a; memset(&a, 0, sizeof(a));
-    a.rows = rows; a.D = D; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p);
+    a.rows = rows; a.D = D; a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.salt = qt_salt_ptr;
     a.dy = dy; a.lddy = lddy; a.xhat = (float*)xhat; a.rstd = (float*)rstd; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
     for (int i = 0; i < n_add; ++i) {
         a.sx[i] = sx[i]; a.drop[i] = (drop[i] && drop_p > 0.f); a.seed[i] = seed[i];

@@ -30,6 +30,13 @@ extern thread_local char qt_err_buf[512];
 
 enum { QT_OK = 0, QT_ERR_RUNTIME = -1, QT_ERR_ARG = -2, QT_ERR_LAUNCH = -3, QT_ERR_UNSUPPORTED = -4 };
 
+// ---- per-step dropout salt ---------------------------------------------------------------------------------------
+// Dropout seeds are kernel ARGUMENTS (one fresh value per site per call from the host counter) — inside a captured HIP graph they are
+// frozen, and every replay would draw the same masks.  A device word set with qt_set_dropout_salt() is therefore added to every seed
+// by the kernels themselves; bumping it (qt_bump_dropout_salt, a one-thread kernel that is part of the captured step) gives every
+// replay fresh masks while forward and backward of one step still agree.  Null (the default): seeds are used as passed.
+extern const unsigned long long* qt_salt_ptr;          // host-side variable of the library (misc.hip); launchers copy it into their kernel arguments
+
 // ---- counter-based dropout RNG ---------------------------------------------
 // Stateless counter RNG over (seed, element index): the backward kernels regenerate the forward mask from
 // the same pair, nothing is stored.  32-bit mixer (two multiply-xorshift rounds, the "lowbias32" constants)

@@ -9,7 +9,9 @@
 // one wave per row; element (r, j) uses dropout index r*L + j
 __global__ __launch_bounds__(256) void qt_softmax_fwd_kernel(const float* __restrict__ s, long lds_, long rows, int L, float scale,
                                                              float drop_p, float inv_keep, unsigned long long seed,
-                                                             float* __restrict__ p, long ldp, float* __restrict__ y, long ldy) {
+                                                             float* __restrict__ p, long ldp, float* __restrict__ y, long ldy,
+                                                             const unsigned long long* __restrict__ salt) {
+    if (salt) seed += *salt;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(256) void qt_softmax_fwd_kernel(const float* __rest
 // ds = scale * p * (dp - sum_j dp_j p_j),  dp = dy * dropout multiplier
 __global__ __launch_bounds__(256) void qt_softmax_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ p, long ldp,
                                                              long rows, int L, float scale, float drop_p, float inv_keep,
-                                                             unsigned long long seed, float* __restrict__ ds, long ldds) {
+                                                             unsigned long long seed, float* __restrict__ ds, long ldds,
+                                                             const unsigned long long* __restrict__ salt) {
+    if (salt) seed += *salt;
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -54,7 +58,7 @@ extern "C" int qt_softmax_fwd(void* stream, const float* s, long lds_, long rows
     QT_CHECK_ARG(s && y && rows > 0 && L > 0 && lds_ >= L && ldy >= L && (!p || ldp >= L), "qt_softmax_fwd: bad arguments");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_softmax_fwd: drop_p=%f", drop_p);
     hipLaunchKernelGGL(qt_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       s, lds_, rows, L, scale, drop_p, 1.0f / (1.0f - drop_p), seed, p, ldp, y, ldy);
+                       s, lds_, rows, L, scale, drop_p, 1.0f / (1.0f - drop_p), seed, p, ldp, y, ldy, qt_salt_ptr);
     QT_CHECK_LAUNCH("qt_softmax_fwd");
     return QT_OK;
 }
@@ -64,7 +68,7 @@ extern "C" int qt_softmax_bwd(void* stream, const float* dy, long lddy, const fl
     QT_CHECK_ARG(dy && p && ds && rows > 0 && L > 0 && lddy >= L && ldp >= L && ldds >= L, "qt_softmax_bwd: bad arguments");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_softmax_bwd: drop_p=%f", drop_p);
     hipLaunchKernelGGL(qt_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       dy, lddy, p, ldp, rows, L, scale, drop_p, 1.0f / (1.0f - drop_p), seed, ds, ldds);
+                       dy, lddy, p, ldp, rows, L, scale, drop_p, 1.0f / (1.0f - drop_p), seed, ds, ldds, qt_salt_ptr);
     QT_CHECK_LAUNCH("qt_softmax_bwd");
     return QT_OK;
 }
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(256) void qt_attn_avg_weights_kernel(const float* _
                                                                   const float* __restrict__ k, long ldk, long kv_is,
                                                                   int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
                                                                   float scale, float drop_p, float inv_keep, unsigned long long seed,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, const unsigned long long* __restrict__ salt) {
+    if (salt) seed += *salt;
     const int lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= (long)n_items * Lq) return;
@@ -122,7 +127,7 @@ extern "C" int qt_attn_avg_weights(void* stream, const float* q, long ldq, long 
     const long waves = (long)n_items * Lq;
     hipLaunchKernelGGL(qt_attn_avg_weights_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        q, ldq, q_is, q_rs, k, ldk, kv_is, n_items, n_kv, kv_shift, H, Lq, Lk, dh, scale, drop_p,
-                       1.0f / (1.0f - drop_p), seed, out);
+                       1.0f / (1.0f - drop_p), seed, out, qt_salt_ptr);
     QT_CHECK_LAUNCH("qt_attn_avg_weights");
     return QT_OK;
 }

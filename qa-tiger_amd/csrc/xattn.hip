@@ -26,7 +26,7 @@ struct XAttnArgs {
     long u_is, u_rs; int n_items, H, Lq, Lk, D;
     int bch, gq;             // backward: rows per staged chunk, (query, head) slots held in LDS
     int swap_ug;             // backward: u and dctx rows share ONE LDS buffer (dctx first, then u) so that two workgroups fit a CU
-    float scale, drop_p, inv_keep; unsigned long long seed;
+    float scale, drop_p, inv_keep; unsigned long long seed; const unsigned long long* salt;
     // backward
     const float* dctx; const float* dasum; const float* ctx_in;
     float* du; float* dx;
@@ -72,6 +72,7 @@ __device__ inline void xa_stage_rows(const float* __restrict__ xbase, float* __r
 
 template <int NV>
 __global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     constexpr int QB = 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
 // registers — with the dX rows kept in registers in between: 75 KiB, two workgroups per CU.
 template <int NV>
 __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     float xmax = 0.f;                                               // max |dx| written by this thread (dx_amax)
     constexpr int QB = 2, GQ = 16;        // (query, head) vectors per pass
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -372,7 +374,7 @@ extern "C" int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, 
     XAttnArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.x = x; a.ctx = ctx; a.lse = lse; a.asum = asum; a.u_is = u_is; a.u_rs = u_rs;
     a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr;
     const size_t lds = sizeof(float) * (size_t)XA_FCH * D;
     const int nvl = (D / 4 + 63) / 64;                              // float4 per lane
     hipStream_t st = (hipStream_t)stream;
@@ -395,7 +397,7 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     XAttnArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.x = x; a.ctx_in = ctx; a.lse = (float*)lse; a.asum = (float*)asum; a.dctx = dctx; a.dasum = dasum;
     a.u_is = u_is; a.u_rs = u_rs; a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.du = du; a.dx = dx; a.dx_amax = dx_amax;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr; a.du = du; a.dx = dx; a.dx_amax = dx_amax;
     const int NQ = Lq * H;
     a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
     size_t lds = 0;

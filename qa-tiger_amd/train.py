@@ -122,6 +122,7 @@ class GradSync:
         self._seen = [False] * n
         self._works = []
         self._fired = [False] * len(self.buckets)
+        self.defer = False                        # True: hooks only place gradients; every bucket is fired by finish() (captured train step)
         self.trace = None                         # set to a list to record ('grad', param index) / ('fire', bucket) / ('finish',) in order
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -140,7 +141,7 @@ class GradSync:
                     self.trace.append(('grad', i))
                 b = self.bucket_of[i]
                 self._pending[b] -= 1
-                if self._pending[b] == 0:
+                if self._pending[b] == 0 and not self.defer:
                     self._fire(b)
         return hook
 
@@ -240,6 +241,19 @@ class FusedAdam(torch.optim.Optimizer):
         ops.weights_epoch += 1                          # parameter memory rewritten by a raw kernel: cached weight images are stale
         return loss
 
+    @torch.no_grad()
+    def step_dev(self, step_dev: Tensor, bc_dev: Tensor, grad_scale: float = 1.0):
+        """The same update with the step count in device memory (`step_dev` int64[1] is incremented by the kernel): the form a
+        captured train step needs, whose kernel arguments are frozen (include/qatiger.h qt_adam_step_dev)."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        rc = ops._lib.load().qt_adam_step_dev(ops._stream(), ops._ptr(self.flat.flat), ops._ptr(self.flat.grad), ops._ptr(self.exp_avg),
+                                             ops._ptr(self.exp_avg_sq), self.flat.flat.numel(), ops._ptr(step_dev), ops._ptr(bc_dev),
+                                             float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(grad_scale),
+                                             float(g['weight_decay']))
+        ops._lib.check(rc, 'qt_adam_step_dev')
+        ops.weights_epoch += 1
+
     def state_dict(self) -> dict:
         for st in self.state.values():
             st['step'] = torch.tensor(float(self.step_count))
@@ -304,6 +318,81 @@ def shard_batch(batch: Dict[str, Tensor], rank: int, world: int) -> Dict[str, Te
             out[k] = v
     return out
 
+
+
+class GraphedTrainStep:
+    """The whole train step of one rank — zero the gradient buffer, forward (dropout on), cross-entropy, backward, Adam — captured ONCE
+    into a HIP graph and replayed.  A step is ~700 kernel launches; at the per-GPU batch of the 8-GPU strong-scaling point (B = 32) the
+    GPU needs ~5 ms for them and Python/ctypes/autograd ~9 ms to issue them, so eager steps are host-bound there; a replay is one launch.
+
+    What makes the step capturable (include/qatiger.h): no runtime memset/memcpy nodes from the library (every zeroing is a kernel), no
+    allocation or synchronisation inside an entry point, dropout seeds salted from a DEVICE word that a one-thread kernel bumps inside the
+    captured step (qt_set_dropout_salt / qt_bump_dropout_salt: fresh masks at every replay, forward and backward of one step still
+    agree), the Adam step count and bias corrections in device memory (qt_adam_step_dev), max|x| records from a pool whose zeroing
+    kernel is part of the capture.  Shapes and the learning-rate hyper-parameters are frozen at capture.
+
+    world > 1: forward + backward are captured, the gradient all-reduce (RCCL) and the optimizer run eagerly after the replay
+    (one replay + one collective per bucket + two launches per step)."""
+
+    SALT_INC = 0x9E3779B97F4A7C15
+
+    def __init__(self, engine: 'DataParallelStep', example: Dict[str, Tensor], warmup: int = 3):
+        self.eng = engine
+        dev = engine.flat.flat.device
+        if dev.type != 'cuda':
+            raise ops._lib.QTError('GraphedTrainStep needs an MI355X (cuda) device')
+        self.distributed = engine.sync.world > 1
+        self.lib = ops._lib.load()
+        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops._lib.check(self.lib.qt_set_dropout_salt(ops._ptr(self.salt)), 'qt_set_dropout_salt')     # library-global: one engine per process
+        self.step_dev = torch.tensor([engine.optim.step_count], dtype=torch.int64, device=dev)
+        self.bc = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.static_in = {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in example.items()}
+        engine.sync.defer = True
+        steps_before = engine.optim.step_count
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                     # lazy initialisation and allocator warm-up outside the capture
+                self._captured_part()
+                self._eager_part()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ops._amax_pool.cur = 0                          # the pool's zeroing kernel must be inside the capture
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._captured_part()
+        engine.optim.step_count = steps_before + warmup      # the capture pass records work, it does not run it
+
+    def _captured_part(self) -> Tensor:
+        eng = self.eng
+        ops._lib.check(self.lib.qt_bump_dropout_salt(ops._stream(), ops._ptr(self.salt), self.SALT_INC), 'qt_bump_dropout_salt')
+        eng.sync.begin()
+        out = eng.model(self.static_in)
+        loss = eng.criterion(out['out'], self.static_in['label'])
+        loss.backward()
+        if not self.distributed:
+            eng.sync.finish()
+            eng.optim.step_dev(self.step_dev, self.bc, grad_scale=1.0)
+        return loss.detach()
+
+    def _eager_part(self) -> None:
+        if self.distributed:
+            eng = self.eng
+            eng.sync.finish()                           # fires every bucket's all-reduce now, waits
+            eng.optim.step_dev(self.step_dev, self.bc, grad_scale=1.0 / eng.sync.world)
+
+    def __call__(self, batch: Dict[str, Tensor]) -> Tensor:
+        for k, v in self.static_in.items():
+            if isinstance(v, Tensor) and batch[k] is not v:
+                v.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        if self.distributed:
+            self._eager_part()
+        else:
+            self.eng.optim.step_count += 1
+            ops.weights_epoch += 1                      # parameter memory changed: host-side caches (weight scales) are stale for eager callers
+        return self.static_loss
 
 
 class GraphedForward:

@@ -446,3 +446,39 @@ def test_graphed_forward_in_a_fresh_process(qt):
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().endswith('OK'), res.stdout[-2000:] + res.stderr[-2000:]
     print(res.stdout)
+
+
+def test_graphed_train_step_matches_eager_and_redraws_dropout(qt, synth):
+    """qt.GraphedTrainStep: the whole train step (zero grads, forward, CE, backward, Adam) replayed from ONE HIP graph.
+    (a) eval mode (no dropout): replays reproduce an eager engine's loss sequence and weights, i.e. the device-side Adam step count and
+        bias corrections advance per replay; (b) train mode with lr = 0: two replays on the same batch give DIFFERENT losses — the
+        dropout masks are salted from device memory, not frozen into the graph — and both are finite."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 8})
+    P = synth.make_state_dict(cfg, 713)
+    batch = to_dev(synth.make_inputs(cfg, 713))
+
+    def engine(train, lr):
+        m = qt.QA_TIGER(**cfg.model_kwargs())
+        m.load_state_dict(P, strict=True)
+        m = m.to(DEV)
+        m.train() if train else m.eval()
+        return qt.DataParallelStep(m, lr=lr, betas=(0.95, 0.999))
+
+    try:
+        eager, graphed = engine(False, 1e-4), engine(False, 1e-4)
+        gs = qt.GraphedTrainStep(graphed, batch, warmup=2)          # 2 eager warm-up steps, then the capture (which records, not runs)
+        for _ in range(2):
+            eager.step(batch)
+        for i in range(3):
+            le, lg = float(eager.step(batch)), float(gs(batch))
+            assert lg == pytest.approx(le, rel=2e-5), (i, le, lg)
+        assert graphed.optim.step_count == eager.optim.step_count == 5
+        d = (graphed.flat.flat - eager.flat.flat).abs()
+        assert float(d.median()) < 1e-7 and float((d > 1e-6).float().mean()) < 0.02      # (Adam turns rounding-noise gradients into +-lr steps)
+        del gs
+        tr = engine(True, 0.0)
+        gs = qt.GraphedTrainStep(tr, batch, warmup=1)
+        losses = [float(gs(batch)) for _ in range(4)]
+        assert all(np.isfinite(losses)) and len(set(round(l, 6) for l in losses)) >= 3, losses
+    finally:
+        qt._lib.load().qt_set_dropout_salt(None)                     # the salt pointer is library-global: do not leak it into other tests

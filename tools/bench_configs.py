@@ -14,11 +14,21 @@ for label, cfg in [('config3 shard (B=32/GPU of the 8-GPU global 256)', synth.Pa
     n = 5
     for _ in range(n): eng.step(batch)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
+    gdt = None
+    if cfg.B <= 64:                                  # host-bound regime: the whole train step as ONE HIP graph (qt.GraphedTrainStep)
+        model.train()
+        gs = qt.GraphedTrainStep(eng, batch)
+        for _ in range(3): gs(batch)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(20): gs(batch)
+        torch.cuda.synchronize(); gdt = (time.perf_counter() - t) / 20
+        del gs
     model.eval()
     with torch.no_grad():
         for _ in range(2): model(batch)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(n): model(batch)
         torch.cuda.synchronize(); ft = (time.perf_counter() - t) / n
-    print('%-62s fwd+bwd %8.2f ms = %7.0f QA/s   fwd %7.2f ms = %7.0f QA/s   peak mem %.1f GB' % (label, dt * 1e3, cfg.B / dt, ft * 1e3, cfg.B / ft, torch.cuda.max_memory_allocated() / 1e9), flush=True)
+    print('%-62s fwd+bwd %8.2f ms = %7.0f QA/s   fwd %7.2f ms = %7.0f QA/s   peak mem %.1f GB' % (label, dt * 1e3, cfg.B / dt, ft * 1e3, cfg.B / ft, torch.cuda.max_memory_allocated() / 1e9)
+          + ('' if gdt is None else '   captured train step %.2f ms = %.0f QA/s' % (gdt * 1e3, cfg.B / gdt)), flush=True)
     del eng, model, batch; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
