@@ -127,7 +127,8 @@ int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
                   const float* sx, const int* drop, const unsigned long long* seed, float drop_p,
                   float* const* dx, const long* lddx, const int* dx_acc,
                   float* dgamma, float* dbeta,
-                  float* const* dx_amax /* nullable; per addend a nullable max|dx_a| record, zeroed by the caller */);
+                  float* const* dx_amax /* nullable; per addend a nullable max|dx_a| record, zeroed by the caller */,
+                  int accumulate_params /* != 0: dgamma / dbeta are ADDED to (slices of a pre-zeroed gradient buffer), not overwritten */);
 
 /* TempMoE router / Gaussian weights (modules.py:565-580, 420-471):
  * logits [B,K], gauss_raw [B,2K] (pairs (u_e, v_e)) -> probs [B,K], topk_inds [B,k] int64

@@ -131,7 +131,7 @@ SIGNATURES = {
     'qt_attn_bwd': [_p, _p, _l, _l, _l, _p, _l, _p, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _p, _l,
                     _i, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p, _p],
     'qt_add_ln_fwd': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _f, _p, _l, _i, _p, _p],
-    'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p],
+    'qt_add_ln_bwd': [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i],
     'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p],
     'qt_moe_coef_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'qt_moe_treduce_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -217,7 +217,7 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
                              const float* dy, long lddy, const float* xhat, const float* rstd, const float* gamma,
                              const float* sx, const int* drop, const unsigned long long* seed, float drop_p,
                              float* const* dx, const long* lddx, const int* dx_acc,
-                             float* dgamma, float* dbeta, float* const* dx_amax) {
+                             float* dgamma, float* dbeta, float* const* dx_amax, int accumulate_params) {
     if (int rc = ln_check("qt_add_ln_bwd", rows, D)) return rc;
     QT_CHECK_ARG(n_add >= 1 && n_add <= LN_MAX_ADD, "qt_add_ln_bwd: n_add=%d", n_add);
     QT_CHECK_ARG(dy && xhat && rstd && gamma && dgamma && dbeta, "qt_add_ln_bwd: null pointer");
@@ -231,8 +231,9 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
         if (dx[i]) QT_CHECK_ARG(qt_aligned16(dx[i]) && lddx[i] % 4 == 0, "qt_add_ln_bwd: dx %d alignment", i);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    if (dbeta == dgamma + D) e = qt_zero_1d(dgamma, 2L * D, st);     // one launch when the two live side by side (ops.py allocates them so)
+    hipError_t e = hipSuccess;
+    if (accumulate_params) {}                                        // dgamma / dbeta hold earlier contributions (a pre-zeroed gradient buffer): add to them
+    else if (dbeta == dgamma + D) e = qt_zero_1d(dgamma, 2L * D, st);     // one launch when the two live side by side (ops.py allocates them so)
     else { e = qt_zero_1d(dgamma, D, st); if (e == hipSuccess) e = qt_zero_1d(dbeta, D, st); }
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_add_ln_bwd: memset: %s", hipGetErrorString(e));
     const int blocks = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);   // 2048 x 4 waves: 32 waves per CU

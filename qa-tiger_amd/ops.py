@@ -924,6 +924,7 @@ class AddLayerNormFn(torch.autograd.Function):
                                        LN_EPS, _ptr(y), D, int(relu_out), _ptr(xhat), _ptr(rstd))
         _lib.check(rc, 'qt_add_ln_fwd')
         ctx.save_for_backward(gamma, xhat, rstd, y if relu_out else None)
+        ctx.params = (gamma, beta)                  # the Parameter objects (for the flat-gradient claim in backward)
         ctx.cfg = (relu_out, drop_p, tuple(scales), tuple(drops), tuple(sds), [x.shape for x in xs])
         return y.reshape(xs[0].shape)
 
@@ -938,8 +939,18 @@ class AddLayerNormFn(torch.autograd.Function):
         rows, D = xhat.shape
         dxs = [torch.empty((rows, D), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[7 + i] else None
                for i in range(n)]
-        dgb = torch.empty((2, D), device=g.device, dtype=torch.float32)      # side by side: zeroed by one launch
-        dgamma, dbeta = dgb[0], dgb[1]
+        acc_params = 0
+        ggv = bgv = None
+        if grads_prezeroed:                          # accumulate straight into the parameters' slices of the (zeroed) flat gradient buffer
+            ggv = _claim_grad_view(ctx.params[0])
+            bgv = _claim_grad_view(ctx.params[1]) if ggv is not None else None
+        if ggv is not None and bgv is not None:
+            dgamma, dbeta, acc_params = ggv[:], bgv[:], 1
+        else:
+            if ggv is not None:
+                grad_claims.discard(id(ctx.params[0]))
+            dgb = torch.empty((2, D), device=g.device, dtype=torch.float32)      # side by side: zeroed by one launch
+            dgamma, dbeta = dgb[0], dgb[1]
         # every dx_i is somebody's dY: its max|.| is measured while it is written (the producing layer's backward GEMMs scale by it)
         ams = [new_amax(g.device) if (d is not None and precision['bwd'] == 'f16x3') else None for d in dxs]
         AM = (C.c_void_p * n)(*[a.data_ptr() if a is not None else None for a in ams])
@@ -950,7 +961,7 @@ class AddLayerNormFn(torch.autograd.Function):
         Dr = (C.c_int * n)(*[int(d) for d in drops])
         Sd = (C.c_ulonglong * n)(*sds)
         rc = _lib.load().qt_add_ln_bwd(_stream(), rows, D, n, _ptr(g), _ld(g), _ptr(xhat), _ptr(rstd), _ptr(gamma),
-                                       S, Dr, Sd, float(drop_p), P, L, Acc, _ptr(dgamma), _ptr(dbeta), AM)
+                                       S, Dr, Sd, float(drop_p), P, L, Acc, _ptr(dgamma), _ptr(dbeta), AM, acc_params)
         _lib.check(rc, 'qt_add_ln_bwd')
         outs = [d.reshape(shp) if d is not None else None for d, shp in zip(dxs, shapes)]
         for o_, a_ in zip(outs, ams):

@@ -1,0 +1,12 @@
+"""One process: N eager train steps at the 8-GPU strong-scaling shard (B=32) — for rocprofv3 --kernel-trace --stats."""
+import importlib, sys, torch
+sys.path.insert(0, '.')
+qt = importlib.import_module('qa-tiger_amd'); synth = qt.synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': B})
+torch.manual_seed(713)
+model = qt.QA_TIGER(**cfg.model_kwargs()).cuda().train()
+eng = qt.DataParallelStep(model)
+batch = synth.fast_device_inputs(cfg, 'cuda', 713)
+for _ in range(6): eng.step(batch)
+torch.cuda.synchronize()
