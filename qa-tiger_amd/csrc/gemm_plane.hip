@@ -681,6 +681,7 @@ __global__ __launch_bounds__(256) void qt_amax_segments_kernel(const float* __re
     const int sgm = blockIdx.y;
     const float* x = flat + off[sgm];
     const long n = cnt[sgm];
+    if ((long)blockIdx.x * 256 >= n) return;                          // block-uniform
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
     __shared__ float red[4];
@@ -693,7 +694,8 @@ extern "C" int qt_amax_segments(void* stream, const float* flat, const long* off
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = qt_zero_1d(amax, (long)n_segments * QT_AMAX_SLOTS, st);
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_amax_segments: zeroing: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(qt_amax_segments_kernel, dim3(8, (unsigned)n_segments), dim3(256), 0, st, flat, offsets, counts, amax);
+    // 64 workgroups per segment (the large weight matrices are ~2.4 M elements; workgroups past a short segment's end fold a 0)
+    hipLaunchKernelGGL(qt_amax_segments_kernel, dim3(64, (unsigned)n_segments), dim3(256), 0, st, flat, offsets, counts, amax);
     QT_CHECK_LAUNCH("qt_amax_segments");
     return QT_OK;
 }

@@ -162,6 +162,102 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
     }
 }
 
+// MFMA forward for the PatchSelecter shape class (at most 16 (query, head) vectors, at most 16 key rows, D a multiple of 128):
+// the two products of an item are small GEMMs — scores S = U X^T (16 x 16 x D) and context C = P X (16 x D x 16) — and the VALU
+// kernel above spends ~23 k wave-instructions per item on them (issue-bound at 44 % of the HBM rate).  Here they run on
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, same arithmetic class as the VALU dot products):
+//   * the D columns are split over the 8 waves in blocks of 16: a wave forms a PARTIAL 16 x 16 score tile over its D/8 columns
+//     straight from global memory (16-byte loads: lane (row, kq) takes columns 4 kq .. 4 kq + 3 of a block, used as the k index
+//     of four MFMAs — the same assignment on both operands, so the products meet), the 8 partial tiles are summed through LDS;
+//   * every wave then holds the full tile in the MFMA result layout (key on the lane, 4 (query, head) rows in registers): softmax
+//     over the keys is four 16-lane shuffle reductions per row, dropout uses the same (row, key) index as the VALU kernel
+//     (the backward regenerates the mask from it);
+//   * the probabilities go through a 1 KiB per-wave LDS tile into operand layout, and the context block of the wave's columns is
+//     computed TRANSPOSED (A = X^T from the LDS-staged rows, B = P^T): a lane ends up with four consecutive columns of one
+//     (query, head) row -> 16-byte stores.
+// LDS: the item's key rows row-major with a 16-float skew (conflict-free 4-byte operand reads), 67 KiB at D = 768: two workgroups per CU.
+typedef float xa_f4 __attribute__((ext_vector_type(4)));
+template <int DB>      // 16-column blocks per wave: D = 128 * DB
+__global__ __launch_bounds__(XA_NT, 2) void qt_xattn_fwd_mfma_kernel(XAttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
+    constexpr int D = 128 * DB, XS = D + 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;                                   // [16][XS]
+    float* Sp = Xs + 16 * XS;                          // [8][16][16] partial score tiles
+    float* Pw = Sp + 8 * 256;                          // [8][16][17] probabilities, one tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.x, NQ = p.Lq * p.H, Lk = p.Lk;
+    const float* xbase = p.x + (long)n * Lk * D;
+    auto urow_of = [&](int qh) { const int qq = min(qh, NQ - 1); const int i = qq / p.H, h = qq - i * p.H;
+                                 return ((long)n * p.u_is + (long)i * p.u_rs) * p.H + h; };
+    // stage the key rows (zero rows past Lk)
+    for (int idx = tid; idx < 16 * (D / 4); idx += XA_NT) {
+        const int row = idx / (D / 4), c4 = idx - row * (D / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < Lk) v = *reinterpret_cast<const float4*>(xbase + (long)row * D + c4 * 4);
+        *reinterpret_cast<float4*>(Xs + row * XS + c4 * 4) = v;
+    }
+    // partial scores over this wave's columns
+    xa_f4 sacc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* up = p.u + urow_of(r16) * D + 4 * kq;
+        const float* xp = xbase + (long)min(r16, Lk - 1) * D + 4 * kq;
+        const bool uok = r16 < NQ, xok = r16 < Lk;
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const int cb = (wave * DB + b) * 16;
+            const float4 ua = uok ? *reinterpret_cast<const float4*>(up + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 xb = xok ? *reinterpret_cast<const float4*>(xp + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.x, xb.x, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.y, xb.y, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.z, xb.z, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.w, xb.w, sacc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Sp[wave * 256 + (4 * kq + reg) * 16 + r16] = sacc[reg];
+    __syncthreads();
+    // full tile in every wave: key = r16 on the lane, (query, head) rows 4 kq + reg in registers
+    float* Pm = Pw + wave * (16 * 17);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int qh = 4 * kq + reg;
+        float sv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sv += Sp[w * 256 + qh * 16 + r16];
+        sv = r16 < Lk ? sv * p.scale : -INFINITY;
+        float m = sv;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float e = r16 < Lk ? __expf(sv - m) : 0.f;
+        float l = e;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+        const long ur = urow_of(qh);
+        if (p.drop_p > 0.f) e *= qt_drop_mult(p.seed, (unsigned long long)ur * Lk + r16, p.drop_p, p.inv_keep);
+        float ls = e;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
+        const float inv = 1.0f / l;
+        Pm[qh * 17 + r16] = e * inv;
+        if (wave == 0 && r16 == 0 && qh < NQ) { p.lse[ur] = m + __logf(l); p.asum[ur] = ls * inv; }
+    }
+    // probabilities in operand layout: B[k = key][col = (query, head)] from lane (qh = r16, key = 4 j + kq)
+    float pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pb[j] = Pm[r16 * 17 + 4 * j + kq];      // (own wave's tile: the LDS writes above are in program order)
+    const long ur16 = urow_of(r16);
+#pragma unroll
+    for (int b = 0; b < DB; ++b) {
+        const int cb = (wave * DB + b) * 16;
+        xa_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(4 * j + kq) * XS + cb + r16], pb[j], acc, 0, 0, 0);
+        if (r16 < NQ) *reinterpret_cast<float4*>(p.ctx + ur16 * D + cb + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // Backward.  Phase 1 (wave per pair of (query, head) vectors, rows staged chunk-wise): recompute
 // a_p = exp(s_p - lse), da_p = dctx·x_p + dasum, ds_p = a_p (mult_p da_p - delta) with
 // delta = dctx·ctx + dasum·asum; dU += ds_p x_p in registers; the scalars a_d[q,p], scale·ds[q,p] and the
@@ -375,9 +471,22 @@ extern "C" int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, 
     a.u = u; a.x = x; a.ctx = ctx; a.lse = lse; a.asum = asum; a.u_is = u_is; a.u_rs = u_rs;
     a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (Lq * H <= 16 && Lk <= 16 && (D == 768 || D == 1024)) {      // the PatchSelecter shape class: both products on the f32 MFMA
+        const size_t mlds = sizeof(float) * ((size_t)16 * (D + 16) + 8 * 256 + 8 * 16 * 17);
+        static bool attr6 = false, attr8 = false;
+        if (D == 768) {
+            if (!attr6) { (void)hipFuncSetAttribute((const void*)qt_xattn_fwd_mfma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); attr6 = true; }
+            hipLaunchKernelGGL(qt_xattn_fwd_mfma_kernel<6>, dim3(n_items), dim3(XA_NT), mlds, st, a);
+        } else {
+            if (!attr8) { (void)hipFuncSetAttribute((const void*)qt_xattn_fwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); attr8 = true; }
+            hipLaunchKernelGGL(qt_xattn_fwd_mfma_kernel<8>, dim3(n_items), dim3(XA_NT), mlds, st, a);
+        }
+        QT_CHECK_LAUNCH("qt_xattn_fwd(mfma)");
+        return QT_OK;
+    }
     const size_t lds = sizeof(float) * (size_t)XA_FCH * D;
     const int nvl = (D / 4 + 63) / 64;                              // float4 per lane
-    hipStream_t st = (hipStream_t)stream;
 #define XA_FWD(NV_) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)qt_xattn_fwd_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          hipLaunchKernelGGL(qt_xattn_fwd_kernel<NV_>, dim3(n_items), dim3(XA_NT), lds, st, a); } while (0)
     if (nvl == 1) XA_FWD(1); else if (nvl == 2) XA_FWD(2); else if (nvl == 3) XA_FWD(3); else XA_FWD(4);

@@ -306,7 +306,9 @@ def test_attention_streaming_dropout_consistency(ops):
 
 
 @pytest.mark.parametrize('n_items,Lq,Lk,E,u_is,u_rs', [(24, 2, 14, 768, 1, 24), (16, 1, 60, 768, 1, 0), (6, 1, 300, 1024, 1, 0),
-                                                      (10, 2, 3, 64, 1, 10), (7, 1, 7, 512, 1, 0)])
+                                                      (10, 2, 3, 64, 1, 10), (7, 1, 7, 512, 1, 0),
+                                                      # the MFMA forward's shape class (<= 16 (query, head) vectors, <= 16 keys, D 768 / 1024):
+                                                      (12, 2, 16, 1024, 1, 12), (9, 2, 5, 768, 1, 9), (6, 1, 9, 768, 1, 0)])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_folded_attention_matches_projected_attention(ops, n_items, Lq, Lk, E, u_is, u_rs, p):
     """K/V-folded few-query attention == nn.MultiheadAttention math with explicit K/V projections (fp64),
@@ -345,6 +347,26 @@ def test_folded_attention_matches_projected_attention(ops, n_items, Lq, Lk, E, u
     gW, gb = mha.in_proj_weight.grad, mha.in_proj_bias.grad
     assert rel(gW[E:], W.grad[E:]) < 1e-4 and rel(gb[2 * E:], b.grad[2 * E:]) < 1e-4
     assert float(gb[:2 * E].abs().max()) == 0 and float(gW[:E].abs().max()) == 0   # q block not used here; key bias has zero true gradient
+
+
+def test_folded_attention_mfma_forward_and_valu_backward_share_the_dropout_mask(ops):
+    """PatchSelecter shape: the forward runs on the f32 MFMA kernel, the backward on the VALU kernel; both must draw the same
+    attention-probability dropout mask from (seed, row, key): first-order check <dO, out(x + d) - out(x)> = <dx, d>."""
+    n_items, Lq, Lk, E, H, p = 20, 2, 14, 768, 8, 0.1
+    torch.manual_seed(1)
+    mha = torch.nn.MultiheadAttention(E, H).to(DEV)
+    q = rnd(n_items * Lq, E, seed=51)
+    x0 = rnd(n_items * Lk, E, seed=52)
+    x = x0.clone().requires_grad_(True)
+    out = ops.folded_attention(q, x, mha, n_items, Lq, Lk, 1, n_items, p, 23)
+    go = rnd(n_items * Lq, E, seed=53)
+    out.backward(go)
+    dlt = 1e-3 * rnd(n_items * Lk, E, seed=54)
+    with torch.no_grad():
+        out2 = ops.folded_attention(q, x0 + dlt, mha, n_items, Lq, Lk, 1, n_items, p, 23)
+    lhs = float(((out2 - out.detach()) * go).sum())
+    rhs = float((x.grad * dlt).sum())
+    assert abs(lhs - rhs) < 2e-2 * max(1e-3, abs(lhs)) + 1e-4, (lhs, rhs)
 
 
 def test_attention_unsupported_shape_fails_loudly(ops, qt):
