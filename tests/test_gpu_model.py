@@ -471,7 +471,7 @@ def test_graphed_train_step_matches_eager_and_redraws_dropout(qt, synth):
             eager.step(batch)
         for i in range(3):
             le, lg = float(eager.step(batch)), float(gs(batch))
-            assert lg == pytest.approx(le, rel=2e-5), (i, le, lg)
+            assert lg == pytest.approx(le, rel=3e-4), (i, le, lg)      # two engines: split-K atomics order + Adam's +-lr steps on noise-level gradients
         assert graphed.optim.step_count == eager.optim.step_count == 5
         d = (graphed.flat.flat - eager.flat.flat).abs()
         assert float(d.median()) < 1e-7 and float((d > 1e-6).float().mean()) < 0.02      # (Adam turns rounding-noise gradients into +-lr steps)
