@@ -606,7 +606,8 @@ class LinearFn(torch.autograd.Function):
             if want_db:
                 bgv = _claim_grad_view(b_param)
                 db = bgv[:] if bgv is not None else torch.empty((n_out,), device=g.device, dtype=torch.float32)
-            gimg = split_image(g, scaled=True, colsum=db)
+            gam = grad_amax(dy, g)                          # measured by dY's producer when it could (attention / LayerNorm / mask kernels)
+            gimg = split_image(g, scaled=gam is None, amax=gam, colsum=db)
             wimg = ctx.wimg
             ximg = SplitImage(x2, x2.shape[0], x2.shape[1], None)
             if ctx.needs_input_grad[0]:
