@@ -38,8 +38,8 @@ else:
 # (and reused by every layer that reads it and by the dW GEMM of the backward), weights are split once per optimizer step, the
 # gradient dY is measured (max|dY|), scaled into fp16's normal range and split once for the dX and dW GEMMs: fp32-equivalent
 # products (3 fp16 MFMAs on 11+11-bit parts) in the forward AND the backward.  QT_PLANE=0 keeps every GEMM on the
-# split-in-the-consumer kernels (gemm_split.hip: fp16 parts forward, bf16 parts backward).
-plane = _os.environ.get('QT_PLANE', '0') != '0'      # and precision['fwd'] == 'f16x3', checked per call: bench.py switches modes at run time
+# split-in-the-consumer kernels (gemm_split.hip, with the same per-tensor scales applied inside the kernel).
+plane = _os.environ.get('QT_PLANE', '1') != '0'      # and precision['fwd'] == 'f16x3', checked per call: bench.py switches modes at run time
 weights_epoch = 0          # bumped whenever parameter memory is rewritten behind autograd's back (train.FusedAdam.step)
 _HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'bf16x1': 3, 'f16x3_t128': 16, 'bf16x3_t128': 17, 'f16x3_t256': 32, 'bf16x3_t256': 33}   # _tNNN: force a tile (A/B testing)
 
@@ -432,7 +432,7 @@ class GradLink:
 
 def _plane_ok(rows: int, n_out: int, k_in: int) -> bool:
     """Shapes the 256x256x32 tile of qt_gemm_ps covers for all three products of a Linear layer (y, dX, dW)."""
-    return plane and precision['fwd'] == 'f16x3' and rows >= 256 and rows % 32 == 0 and n_out >= 128 and n_out % 32 == 0 and k_in >= 128 and k_in % 32 == 0
+    return plane and precision['fwd'] == 'f16x3' and precision['bwd'] == 'f16x3' and rows >= 256 and rows % 32 == 0 and n_out >= 128 and n_out % 32 == 0 and k_in >= 128 and k_in % 32 == 0
 
 
 def weight_image(weight: Tensor) -> Optional[SplitImage]:
