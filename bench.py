@@ -80,7 +80,8 @@ def pmc_traffic(family):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', name)
         try:
             with open(path) as f:
-                return round(json.load(f)[family]['hbm_bytes_per_launch']), name
+                d = json.load(f)
+                return round(d[family if family in d else family + '_x3']['hbm_bytes_per_launch']), name
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -316,11 +317,19 @@ def main():
         top = sorted(gm['by_detail'].items(), key=lambda kv: -kv[1][0])[:4]
         split = ops.precision['fwd'] != 'fp32'
         peak = PEAK_16BIT_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        ps_n = sum(v[2] for k, v in gm['by_detail'].items() if k[5] == 'ps')
+        sp = summ.get('split', dict(ms=0.0, launches=0))          # operand passes of the pre-split pipeline: split / max|x| launches
+        sp_ms = sp['ms'] / n
+        tf_incl = GFLOP_FWD_BWD * 1e9 * cfg.B / ((gemm_ms + sp_ms) * 1e-3) / 1e12
         roofline = dict(bound='mfma',
-                        kernel=('qt_gemm_x3_kernel' if split else 'qt_gemm_f32_kernel') +
+                        kernel=(('qt_gemm_ps_kernel + qt_gemm_x3_kernel' if ps_n else 'qt_gemm_x3_kernel') if split else 'qt_gemm_f32_kernel') +
                                ' (all projection/MLP GEMM launches of one train step, fwd+bwd)',
                         achieved=round(algo_tf, 2), peak=peak, unit='TFLOP/s', frac=round(algo_tf / peak, 4),
-                        traffic=pmc_traffic('gemm_x3')[0] if split else None,
+                        # the pre-split pipeline moves the fp32 -> (hi | lo) split out of the GEMMs into streaming passes (HBM-bound, one
+                        # per tensor, shared by its consumers); charged to the GEMM family they give the stricter figure below
+                        operand_passes=dict(ms_per_step=round(sp_ms, 3), launches_per_step=sp['launches'] // n,
+                                            achieved_incl=round(tf_incl, 2), frac_incl=round(tf_incl / peak, 4)),
+                        traffic=pmc_traffic('gemm')[0] if split else None,
                         note=('achieved = reference-executed fp32 GEMM FLOPs (34.647 GFLOP/sample) / summed GEMM kernel time; '
                               'each fp32 product is issued as 3 16-bit MFMA products, so the matrix pipes see 3x executed_tflops'
                               if split else 'fp32 MFMA'),
@@ -328,15 +337,17 @@ def main():
                         mfma_issue_frac=round((3.0 if split else 1.0) * exec_tf / peak, 4),
                         algorithmic_bytes_per_launch=round(sum(4.0 * (k[0] * k[2] + k[2] * k[1] + k[0] * k[1]) * (k[6] if len(k) > 6 else 1) * v[2]
                                                                for k, v in gm['by_detail'].items()) / gm['launches']),
-                        traffic_source=f'profiles/{pmc_traffic("gemm_x3")[1]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --skip-fwd-only`, '
+                        traffic_source=f'profiles/{pmc_traffic("gemm")[1]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --skip-fwd-only`, '
                                        'tools/pmc_step_traffic.sh; FETCH_SIZE x2 per the gfx950 correction; average HBM-side bytes per split-GEMM launch of a train step; '
                                        'PMC counters cannot be read inside an unprofiled run, so this is the committed summary, not a live value)',
                         launches_per_step=gm['launches'] // n, avg_launch_ms=round(gemm_ms / (gm['launches'] / n), 4),
                         # the qt_gemm_x3_kernel launches alone (the family also counts the small exact-fp32 launches):
                         # this is the figure to compare with the rocprofv3 kernel_stats average of qt_gemm_x3_kernel
-                        x3_launches_per_step=sum(v[2] for k, v in gm['by_detail'].items() if k[5] != 'fp32') // n,
-                        x3_avg_launch_ms=round(sum(v[0] for k, v in gm['by_detail'].items() if k[5] != 'fp32') /
-                                               max(1, sum(v[2] for k, v in gm['by_detail'].items() if k[5] != 'fp32')), 4),
+                        ps_launches_per_step=ps_n // n,
+                        ps_avg_launch_ms=round(sum(v[0] for k, v in gm['by_detail'].items() if k[5] == 'ps') / max(1, ps_n), 4),
+                        x3_launches_per_step=sum(v[2] for k, v in gm['by_detail'].items() if k[5] not in ('fp32', 'ps')) // n,
+                        x3_avg_launch_ms=round(sum(v[0] for k, v in gm['by_detail'].items() if k[5] not in ('fp32', 'ps')) /
+                                               max(1, sum(v[2] for k, v in gm['by_detail'].items() if k[5] not in ('fp32', 'ps'))), 4),
                         gemm_ms_per_step=round(gemm_ms, 3), share_of_step=round(gemm_ms / ms_step, 3),
                         top_shapes=[dict(MNK_tAtB=list(k), ms_per_step=round(v[0] / n, 3), launches=v[2] // n,
                                          tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 1)) for k, v in top])

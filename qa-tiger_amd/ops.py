@@ -197,7 +197,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
         if rc == 0:
             return out
         if rc == 2:                                    # done, but a split-K launch could not measure max|C|: one explicit pass
-            _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1), 'qt_amax_f32')
+            _lib.check(_launch('split', 4.0 * out.numel(), ('amax',) + tuple(out.shape), lambda: _lib.load().qt_amax_f32(
+                _stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1)), 'qt_amax_f32')
             return out
         if rc != -4:                                   # -4: shape not handled by the split kernel -> exact fp32 kernel
             _lib.check(rc, 'qt_gemm_x3')
@@ -214,7 +215,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
     if a_colsum is not None:                           # the fp32 kernel has no fused column sum
         _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), 0), 'qt_colsum')
     if c_amax is not None:                             # ... and does not measure max|C|: one explicit pass into the caller's record
-        _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1), 'qt_amax_f32')
+        _lib.check(_launch('split', 4.0 * out.numel(), ('amax',) + tuple(out.shape), lambda: _lib.load().qt_amax_f32(
+            _stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1)), 'qt_amax_f32')
     return out
 
 
@@ -269,7 +271,8 @@ def amax_of(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     _dev(x)
     if out is None:
         out = _amax_pool.take(x.device)
-    _lib.check(_lib.load().qt_amax_f32(_stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), 0), 'qt_amax_f32')
+    _lib.check(_launch('split', 4.0 * x.numel(), ('amax',) + tuple(x.shape), lambda: _lib.load().qt_amax_f32(
+        _stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), 0)), 'qt_amax_f32')
     return out
 
 
@@ -334,7 +337,8 @@ def quant_fp8(x: Tensor, amax: Optional[Tensor] = None) -> SplitImage:
     if amax is None:
         amax = amax_of(x)
     img = torch.empty((R, Cc), device=x.device, dtype=torch.uint8)
-    _lib.check(_lib.load().qt_quant_fp8(_stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), Cc), 'qt_quant_fp8')
+    _lib.check(_launch('split', 5.0 * R * Cc, ('fp8', R, Cc), lambda: _lib.load().qt_quant_fp8(
+        _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), Cc)), 'qt_quant_fp8')
     return SplitImage(img, R, Cc, amax)
 
 
