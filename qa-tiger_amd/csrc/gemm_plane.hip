@@ -86,13 +86,18 @@ template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_
 // FMT 1: e4m3 fp8 lines, 128 k per 128-byte line, ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 64 k (unit block scales): BASELINE
 //        configs[4] ("fp8 MFMA on projection GEMMs"); row-form operands only (forward GEMMs).  Same tile, same LDS map, same DMA
 //        schedule: a K step is always one 128-byte line per row.
-template <bool AKS, bool BKS, bool SWAP, int FMT>
+// WMT: 32-row MFMA tiles per wave along M.  4 = the 256-row tile; 3 = a 192-row tile for problems whose 256-row tiling leaves the last
+//      round of the persistent walk mostly empty (M = 30720, N = 768: 360 tiles on 256 CUs = 2 rounds at 70 %; 480 tiles of 192 rows = 94 %).
+//      Row-form fp16 A operands only; the B tile, the LDS map and the stage pitch are unchanged (an A stage just uses 24 of its 32 KiB).
+template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4>
 __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
     constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
-    constexpr int WMT = 4, WNT = 2, NWN = 4;          // wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32
-    constexpr int BM = 256, BN = 256, GM = 4;
+    static_assert(WMT == 4 || (WMT == 3 && !AKS && FMT == 0), "the 192-row tile exists for row-form fp16 A operands only");
+    constexpr int WNT = 2, NWN = 4;                   // wave tile (32 WMT) x 64 = WMT x 2 MFMA tiles of 32 x 32
+    constexpr int BM = 2 * WMT * 32, BN = 256, GM = 4;
+    constexpr int NS = 2 * WMT;                       // compute segments per K step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,11 +127,11 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     };
 
     // ---- per-lane DMA source offsets (bytes from the operand base), 4 pieces of 1 KiB per operand per wave
-    unsigned offA[4], offB[4];
+    unsigned offA[WMT], offB[4];
     auto set_offsets = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = wave * 4 + i;                         // piece 0..31 of the 32 KiB tile
+        for (int i = 0; i < WMT; ++i) {
+            const int pc = wave * WMT + i;                       // piece 0..8*WMT-1 of the A tile
             if (!AKS) {                                          // rows pc*8 .. pc*8+7, one 128-B line each
                 const int row = pc * 8 + (lane >> 3);
                 const int sl = (lane & 7) ^ ((row >> 1) & 7);
@@ -136,6 +141,10 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
                 const int blk = min((m0 >> 5) + (unit >> 1), (p.M >> 5) - 1);
                 offA[i] = (unsigned)((long)pc * p.lda + blk * 128 + (unit & 1) * 64 + (lane & 3) * 16);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave * 4 + i;                         // piece 0..31 of the 32 KiB B tile
             if (!BKS) {
                 const int row = pc * 8 + (lane >> 3);
                 const int sl = (lane & 7) ^ ((row >> 1) & 7);
@@ -149,13 +158,13 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     };
     auto dma_a = [&](int k0, int stage) {
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 / KS) * 128;
-        const unsigned la = lds0 + stage * P_OPER + wave * 4096;
+        const unsigned la = lds0 + stage * P_OPER + wave * (WMT * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
+        for (int i = 0; i < WMT; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
     auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 / KS) * 128;
-        qt_dma16(lds0 + stage * P_OPER + wave * 4096 + i * 1024, sa, offA[i]);
+        qt_dma16(lds0 + stage * P_OPER + wave * (WMT * 1024) + i * 1024, sa, offA[i]);
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
         const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (!AKS) fa[c] = (unsigned)((wm * 128 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);   // c = hl*2 + s
+            if (!AKS) fa[c] = (unsigned)((wm * (WMT * 32) + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);   // c = hl*2 + s
             else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 8) * 64 + ((c ^ q) * 64));   // c = unit & 3
             if (!BKS) fb[c] = (unsigned)((wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
             else      fb[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                     // c = q*2 + half
             const int slot = 4 * (c >> 1) + 2 * h + (c & 1);
-            fa8[c] = (unsigned)((wm * 128 + r) * 128 + ((slot ^ x) * 16));
+            fa8[c] = (unsigned)((wm * (WMT * 32) + r) * 128 + ((slot ^ x) * 16));
             fb8[c] = (unsigned)((wn * 64 + r) * 128 + ((slot ^ x) * 16));
         }
     }
@@ -242,10 +251,10 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         };
         load_b(0, bh[0], bl[0]);
         load_a(0, 0, ah[0], al[0]);
-        p_static_for<8>([&](auto SEG) {
-            constexpr int seg = decltype(SEG)::value, s = seg >> 2, i = seg & 3, cur = seg & 1;
-            if constexpr (seg + 1 < 8) {
-                constexpr int s1 = (seg + 1) >> 2, i1 = (seg + 1) & 3;
+        p_static_for<NS>([&](auto SEG) {
+            constexpr int seg = decltype(SEG)::value, s = seg / WMT, i = seg % WMT, cur = seg & 1;
+            if constexpr (seg + 1 < NS) {
+                constexpr int s1 = (seg + 1) / WMT, i1 = (seg + 1) % WMT;
                 if constexpr (i1 == 0) load_b(s1, bh[s1], bl[s1]);
                 load_a(s1, i1, ah[cur ^ 1], al[cur ^ 1]);
             }
@@ -280,10 +289,10 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
         };
         load_b(0, b0[0], b1[0]);
         load_a(0, 0, a0[0], a1[0]);
-        p_static_for<8>([&](auto SEG) {
-            constexpr int seg = decltype(SEG)::value, q = seg >> 2, i = seg & 3, cur = seg & 1;
-            if constexpr (seg + 1 < 8) {
-                constexpr int q1 = (seg + 1) >> 2, i1 = (seg + 1) & 3;
+        p_static_for<NS>([&](auto SEG) {
+            constexpr int seg = decltype(SEG)::value, q = seg / WMT, i = seg % WMT, cur = seg & 1;
+            if constexpr (seg + 1 < NS) {
+                constexpr int q1 = (seg + 1) / WMT, i1 = (seg + 1) % WMT;
                 if constexpr (i1 == 0) load_b(q1, b0[q1], b1[q1]);
                 load_a(q1, i1, a0[cur ^ 1], a1[cur ^ 1]);
             }
@@ -332,23 +341,31 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             // reads (A(t): two steps old, B(t): one step old) are the 4 pieces of A(t+1) — if that was issued at all.  The first
             // step of a tile also drains the previous tile's write-out (in-order counter; a counted wait would need the exact
             // number of stores, which ragged tiles make data-dependent).
-            if (t > 0 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t > 0 && t + 1 < nk) {
+                if constexpr (WMT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
             const bool do_b = (t + 1 < nk) && !(p.debug & 2), do_a = (t + 2 < nk) && !(p.debug & 2);
             const int kb1 = kbeg + (t + 1) * KS, ka2 = kbeg + (t + 2) * KS;
             const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
-            auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), pieces 4-7: A(t+2) — this order is what vmcnt(4) counts on
+            auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), then the WMT pieces of A(t+2) — this order is what vmcnt(WMT) counts on
                 constexpr int seg = decltype(SEG)::value;
                 if constexpr (seg < 4) { if (do_b) dma_b1(kb1, stb, seg); }
-                else { if (do_a) dma_a1(ka2, sta, seg - 4); }
+                else {
+                    if (do_a) dma_a1(ka2, sta, seg - 4);
+                    if constexpr (seg == NS - 1) {             // 192-row tile: 6 segments carry 4 + 3 pieces, the last one two
+#pragma unroll
+                        for (int e = NS - 4; e < WMT; ++e) if (do_a) dma_a1(ka2, sta, e);
+                    }
+                }
             };
             if (!(p.debug & 4)) {
                 if constexpr (FMT == 1) compute8((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
                 else compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
             }
-            else p_static_for<8>([&](auto SEG) { issue(SEG); });
+            else p_static_for<NS>([&](auto SEG) { issue(SEG); });
             sa_cur = nxt3(sa_cur);
             ++gb;
         }
@@ -794,25 +811,37 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QT_PS_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "%s: split_k>1 needs a linear epilogue", who);
-    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-    const long tiles = (long)tiles_m * tiles_n;
+    // Tile height (256 or 192 rows) and split-K by one cost model: rounds of the persistent walk x (K steps + fixed per-tile cost),
+    // in units of one K step of a 256-row tile.  The 192-row tile does 3/4 of the work per step at slightly worse operand reuse (+5 %).
+    const int tiles_n = (N + 255) / 256;
     const long slots = 256;
-    a.tiles_m = tiles_m; a.tiles_n = tiles_n;
-    if (split_k <= 0) {
-        split_k = 1;
-        if (plain_epilogue && tiles < 2 * slots && K >= 16 * KS) {      // same cost model as qt_gemm_x3
-            const long ovh = 16;
-            long maxs = K / (4 * KS);
-            if (maxs > 64) maxs = 64;
-            long best = -1;
-            for (long s = 1; s <= maxs; ++s) {
-                const long rounds = (tiles * s + slots - 1) / slots;
+    const long ovh = 16;
+    int force_wmt = 0;                                   // QT_PS_WMT=3|4 pins the tile height (tests, A/B runs); read per call
+    { const char* e = getenv("QT_PS_WMT"); if (e) force_wmt = atoi(e); }
+    const bool wmt3_ok = fmt == 0 && !a_kslow && force_wmt != 4;
+    int wmt = 4;
+    {
+        const bool fixed_split = split_k > 0;
+        long best = -1;
+        int best_s = fixed_split ? split_k : 1;
+        for (int cand = 4; cand >= 3; --cand) {
+            if (cand == 3 && !wmt3_ok) break;
+            if (cand == 4 && force_wmt == 3 && wmt3_ok) continue;
+            const long tl = (long)((M + 64 * cand - 1) / (64 * cand)) * tiles_n;
+            long maxs = 1;
+            if (!fixed_split && plain_epilogue && tl < 2 * slots && K >= 16 * KS) { maxs = K / (4 * KS); if (maxs > 64) maxs = 64; }
+            for (long s = fixed_split ? split_k : 1; s <= (fixed_split ? split_k : maxs); ++s) {
+                const long rounds = (tl * s + slots - 1) / slots;
                 const long ksteps = ((K + s - 1) / s + KS - 1) / KS;
-                const long cost = rounds * (ksteps + ovh);
-                if (best < 0 || cost < best) { best = cost; split_k = (int)s; }
+                const long cost = rounds * (ksteps + ovh) * (cand == 4 ? 100 : 79);      // 79 = 75 x 1.05
+                if (best < 0 || cost < best) { best = cost; best_s = (int)s; wmt = cand; }
             }
         }
+        split_k = best_s;
     }
+    const int tiles_m = (M + 64 * wmt - 1) / (64 * wmt);
+    const long tiles = (long)tiles_m * tiles_n;
+    a.tiles_m = tiles_m; a.tiles_n = tiles_n;
     int kps = (K + split_k - 1) / split_k;
     kps = ((kps + KS - 1) / KS) * KS;
     split_k = (K + kps - 1) / kps;
@@ -834,6 +863,9 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
         QT_PS_ATTR(false, false, true, 0); QT_PS_ATTR(false, true, true, 0); QT_PS_ATTR(true, false, true, 0); QT_PS_ATTR(true, true, true, 0);
         QT_PS_ATTR(false, false, false, 1); QT_PS_ATTR(false, false, true, 1);
 #undef QT_PS_ATTR
+#define QT_PS_ATTR3(BK_, SW_) (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, BK_, SW_, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        QT_PS_ATTR3(false, false); QT_PS_ATTR3(false, true); QT_PS_ATTR3(true, false); QT_PS_ATTR3(true, true);
+#undef QT_PS_ATTR3
         ps_attr_done = true;
     }
 #define QT_PS(AK_, BK_)                                                                                       \
@@ -841,14 +873,21 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
         if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, true, 0>), grid, dim3(512), lds, st, a);     \
         else hipLaunchKernelGGL((qt_gemm_ps_kernel<AK_, BK_, false, 0>), grid, dim3(512), lds, st, a);         \
     } while (0)
+#define QT_PS3(BK_)                                                                                           \
+    do {                                                                                                      \
+        if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<false, BK_, true, 0, 3>), grid, dim3(512), lds, st, a);  \
+        else hipLaunchKernelGGL((qt_gemm_ps_kernel<false, BK_, false, 0, 3>), grid, dim3(512), lds, st, a);      \
+    } while (0)
     if (fmt == 1) {
         if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<false, false, true, 1>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((qt_gemm_ps_kernel<false, false, false, 1>), grid, dim3(512), lds, st, a);
-    } else if (!a_kslow && !b_kslow) QT_PS(false, false);
+    } else if (wmt == 3) { if (b_kslow) QT_PS3(true); else QT_PS3(false); }
+    else if (!a_kslow && !b_kslow) QT_PS(false, false);
     else if (!a_kslow && b_kslow) QT_PS(false, true);
     else if (a_kslow && !b_kslow) QT_PS(true, false);
     else QT_PS(true, true);
 #undef QT_PS
+#undef QT_PS3
     QT_CHECK_LAUNCH(who);
     return QT_OK;
 }

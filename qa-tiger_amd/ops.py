@@ -434,9 +434,14 @@ class GradLink:
         self.res = None          # the tensor object autograd carries to the residual's producer: the accumulating dX GEMM tags it with max|sum|
 
 
+# below this many rows a Linear stays on the split-in-the-consumer kernels: a handful of 256x256 tiles leaves the chip idle and
+# the operand passes are pure launch latency there (measured: 256-row layers 28 us on qt_gemm_ps vs 17 us on qt_gemm_x3's 64-row tiles)
+plane_min_rows = int(_os.environ.get('QT_PLANE_MIN_ROWS', '2048'))
+
+
 def _plane_ok(rows: int, n_out: int, k_in: int) -> bool:
     """Shapes the 256x256x32 tile of qt_gemm_ps covers for all three products of a Linear layer (y, dX, dW)."""
-    return plane and precision['fwd'] == 'f16x3' and precision['bwd'] == 'f16x3' and rows >= 256 and rows % 32 == 0 and n_out >= 128 and n_out % 32 == 0 and k_in >= 128 and k_in % 32 == 0
+    return plane and precision['fwd'] == 'f16x3' and precision['bwd'] == 'f16x3' and rows >= max(256, plane_min_rows) and rows % 32 == 0 and n_out >= 128 and n_out % 32 == 0 and k_in >= 128 and k_in % 32 == 0
 
 
 def weight_image(weight: Tensor) -> Optional[SplitImage]:
@@ -501,7 +506,9 @@ def input_image(x: Tensor, x2: Tensor) -> SplitImage:
             and not torch.cuda.is_current_stream_capturing():
         return cached[1]
     with torch.no_grad():
-        img = split_image(x2.detach())
+        # robust-range mode: activations beyond fp16's range are scaled by their max|x| first (act_amax); by default the parts are unscaled
+        am = act_amax(x, x2)
+        img = split_image(x2.detach(), scaled=am is not None, amax=am)
     x._qt_img = ((x._version, x.data_ptr()), img)
     return img
 

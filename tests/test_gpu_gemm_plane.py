@@ -97,6 +97,32 @@ def test_gemm_ps_split_k_and_epilogues(ops):
     assert torch.equal(d1 == 0, d2 == 0) and rel(d1, d2) < 1e-5
 
 
+@pytest.mark.parametrize('wmt', [3, 4])
+def test_gemm_ps_both_tile_heights(ops, wmt, monkeypatch):
+    """The launcher picks the 192-row (WMT 3) or the 256-row (WMT 4) tile by its cost model; QT_PS_WMT pins it.  Row-form A
+    operands on both heights: ragged M, several rounds of the persistent walk (> 256 tiles), the dX orientation, every epilogue,
+    split-K atomics — all against fp64 and bit-identical dropout masks across the two heights."""
+    monkeypatch.setenv('QT_PS_WMT', str(wmt))
+    for (M, N, K, bks) in [(1000, 256, 96, False), (192 * 7 + 5, 384, 160, True), (256 * 9, 256 * 40, 64, False), (2048, 128, 2048, False)]:
+        a, b = rnd(M, K, seed=11), rnd(*((K, N) if bks else (N, K)), seed=12)
+        out = ops.gemm_ps(ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV)), b_kslow=bks)
+        ref = a.double() @ (b.double() if bks else b.double().t())
+        assert rel(out, ref) < 2e-6, (M, N, K, bks)
+    x, w = rnd(1200, 256, seed=7), rnd(320, 256, seed=8)
+    bias, res = rnd(320, seed=9), rnd(1200, 320, seed=10)
+    ix, iw = ops.split_image(x.to(DEV)), ops.split_image(w.to(DEV))
+    o = ops.gemm_ps(ix, iw, bias=bias.to(DEV), add=res.to(DEV), relu=1)
+    assert rel(o, torch.relu(x.double() @ w.double().t() + bias.double() + res.double())) < 2e-6
+    acc = res.clone().to(DEV)
+    ops.gemm_ps(ix, iw, out=acc, accumulate=True, alpha=0.5)
+    assert rel(acc, res.double() + 0.5 * (x.double() @ w.double().t())) < 2e-6
+    for sk in (1, 3):
+        assert rel(ops.gemm_ps(ix, iw, split_k=sk), x.double() @ w.double().t()) < 2e-6
+    d1 = ops.gemm_ps(ix, iw, drop_p=0.1, seed=77)
+    d2 = ops.gemm(x.to(DEV), w.to(DEV), drop_p=0.1, seed=77, mode='f16x3')
+    assert torch.equal(d1 == 0, d2 == 0) and rel(d1, d2) < 1e-5
+
+
 @pytest.mark.parametrize('sa,sb', [(1e-7, 1.0), (1e5, 1e-4), (3e-9, 2e-5), (1e3, 1e3)])
 def test_gemm_ps_scaled_operands_any_magnitude(ops, sa, sb):
     """Gradient-like (1e-7..1e-9), tiny-weight (1e-4) and huge-activation (1e5) operands: with the per-tensor power-of-two scale

@@ -11,7 +11,8 @@ for _ in range(2): eng.step(batch)
 ops.timer = ops.KernelTimer(); n = 2
 for _ in range(n): eng.step(batch)
 summ = ops.timer.summary(); ops.timer = None
-for fam in ('gemm', 'attn_fwd', 'attn_bwd'):
+for fam in ('gemm', 'split', 'attn_fwd', 'attn_bwd'):
+    if fam not in summ: continue
     d = summ[fam]; print('== %s: %.2f ms/step, %d launches' % (fam, d['ms'] / n, d['launches'] // n))
     rows = sorted(d['by_detail'].items(), key=lambda kv: -kv[1][0])
     acc = 0
