@@ -111,7 +111,7 @@ int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, const float
 int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
                  const float* ctx, const float* lse, const float* asum, const float* dctx, const float* dasum,
                  int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
-                 float* du, float* dx, float* dx_amax /* nullable: max|dx| record */);
+                 float* du, float* dx, float* dx_amax /* nullable: max|dx| record */, float* du_amax /* nullable: max|du| record */);
 
 /* y = LayerNorm(sum_i sx[i] * dropout_i(x[i])) (+ optional ReLU on y); n_add <= 4.
  * Replaces modules.py:223-229, 233-235, 344-346, 603, 612, 713-716.
@@ -178,7 +178,7 @@ int qt_adam_step_dev(void* stream, float* param, const float* grad, float* exp_a
 /* max |x| over an fp32 [R, C] tensor (row pitch ldx elements) into a device RECORD of 64 floats (256 bytes): each workgroup folds its
  * maximum into slot (block index & 63) with one atomic max on the bit pattern, consumers take the maximum of the 64 slots.  Every
  * `amax` argument of this header is such a 64-float record.  zero_first != 0 clears the record first, 0 folds into an earlier one.
- * Kernels that fill a record as a by-product (qt_gemm_x3 c_amax, qt_attn_bwd g_amax, qt_xattn_bwd dx_amax) expect it ZEROED by the
+ * Kernels that fill a record as a by-product (qt_gemm_x3 / qt_gemm_ps c_amax, qt_attn_bwd g_amax, qt_xattn_bwd dx_amax / du_amax) expect it ZEROED by the
  * caller (the host side hands out records from a pool it zeroes half at a time: no per-record launch). */
 int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* amax, int zero_first);
 /* the same for n_segments tensors of one flat buffer in one launch: amax[s] = max |flat[offsets[s] .. offsets[s] + counts[s])|
@@ -194,12 +194,17 @@ int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const fl
  *   a_kslow = 0: A image holds [M rows][K];  a_kslow = 1: [K rows][M]  (dW = dY^T X reads dY and X this way)
  *   b_kslow = 0: B image holds [N rows][K] (nn.Linear weight layout);  b_kslow = 1: [K rows][N]
  * a_amax / b_amax: the device floats the images were scaled by (nullable = unscaled).
- * K must be a multiple of 32 (and M / N of a K-slow operand); returns -4 without touching C when the shape does not fit. */
+ * K must be a multiple of 32 (and M / N of a K-slow operand); returns -4 without touching C when the shape does not fit.
+ * c_amax (nullable): a zeroed max|x| record (64 floats) that receives max|C| of the values as stored (after the whole epilogue,
+ * `accumulate` included), so the next GEMM that takes C as its gradient operand needs no pass of its own; a split-K launch
+ * (atomics) cannot know it and returns 2 with the record untouched.
+ * Tile height: 256 rows, or 192 for row-form A operands when that fills the last round of the persistent walk better
+ * (QT_PS_WMT=3|4 in the environment pins it). */
 int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
                const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                const float* mask_src, long ld_mask, float mask_scale,
-               float drop_p, unsigned long long drop_seed, int accumulate, int split_k);
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax);
 
 /* ---- BASELINE configs[4] ("fp8 MFMA on projection GEMMs"): e4m3 operand images and the GEMM on
  * v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 accumulate, fp32 epilogue).  Outside the 1e-3 parity gate by construction: judged by

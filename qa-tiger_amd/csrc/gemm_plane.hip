@@ -56,6 +56,7 @@ struct PlaneArgs {
     float* C; long ldc;
     float alpha;
     const float* a_amax; const float* b_amax;   // nullable: max|x| the operand's image was scaled by (qt_split_f16)
+    float* c_amax;                              // nullable: record that receives max|C| as written (never with split-K atomics)
     const float* bias;
     const float* add_src; long ld_add;
     int relu;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     }
 
     floatx16 acc[WMT][WNT];
+    float cmax = 0.f;                                  // max |C| stored by this lane over all its tiles (c_amax)
     auto lds_u4 = [&](unsigned off) -> uint4 { return *reinterpret_cast<const uint4*>(smem + off); };
     auto lds_tr = [&](unsigned off) -> uint2 {
         const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)(lds0 + off));
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
                                             v *= qt_drop_mult(p.drop_seed, (unsigned long long)m * (unsigned long long)p.N + (ncol0 + j * 32), p.drop_p, p.inv_keep);
                                         v += oldv[e8][j];
                                     }
+                                    cmax = fmaxf(cmax, fabsf(v));
                                     crow[j * 32] = v;
                                 }
                             });
@@ -502,7 +505,10 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
                             }
                             v[0] += oldv[g].x; v[1] += oldv[g].y; v[2] += oldv[g].z; v[3] += oldv[g].w;
                         }
-                        if (m < p.M && n < p.N) *reinterpret_cast<float4*>(p.C + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (m < p.M && n < p.N) {
+                            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                            *reinterpret_cast<float4*>(p.C + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
                     });
                 });
             });
@@ -519,6 +525,14 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             else epilogue(std::false_type{}, std::false_type{});
         }
         if (!more) break;
+    }
+    if (p.c_amax) {                                    // one atomic per wave per launch (NaN propagates: it orders above every float)
+        bool bad = cmax != cmax;
+        cmax = qt_wave_max(bad ? 0.f : cmax);
+        bad = __any(bad);
+        if (bad) cmax = __builtin_nanf("");
+        if (lane == 0 && (cmax > 0.f || bad))
+            atomicMax(reinterpret_cast<unsigned*>(p.c_amax) + ((blockIdx.x * 8 + wave) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, cmax));
     }
 }
 
@@ -788,7 +802,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
                       const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                       float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                       const float* mask_src, long ld_mask, float mask_scale,
-                      float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+                      float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax) {
     const int KS = fmt == 1 ? 128 : PBK;
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "%s: bad problem", who);
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "%s: drop_p=%f", who, drop_p);
@@ -846,6 +860,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     kps = ((kps + KS - 1) / KS) * KS;
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
+    a.c_amax = split_k > 1 ? nullptr : c_amax;       // partial sums are not the values of C: the caller measures it (return 2)
     if (split_k > 1 && !accumulate) {
         hipError_t e = qt_zero_2d(C, ldc, M, N, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "%s: zeroing C: %s", who, hipGetErrorString(e));
@@ -889,7 +904,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
 #undef QT_PS
 #undef QT_PS3
     QT_CHECK_LAUNCH(who);
-    return QT_OK;
+    return (c_amax && split_k > 1) ? 2 : QT_OK;
 }
 
 // C[M,N] = epilogue(alpha/(s_a s_b) * op(A) op(B)) on split images.
@@ -900,9 +915,9 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
                           const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                           float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
-                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax) {
     return plane_gemm("qt_gemm_ps", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
-                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k);
+                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, c_amax);
 }
 
 // BASELINE configs[4]: C[M,N] = epilogue(alpha/(s_a s_b) * A B^T) with A [M rows][K] and B [N rows][K] (nn.Linear weight) given as
@@ -914,7 +929,7 @@ extern "C" int qt_gemm_f8(void* stream, int M, int N, int K, float alpha,
                           const float* mask_src, long ld_mask, float mask_scale,
                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k) {
     return plane_gemm("qt_gemm_f8", 1, stream, 0, 0, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
-                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k);
+                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, nullptr);
 }
 
 // fp32 [R, C] -> e4m3 image [R][C bytes] (row pitch ld_img bytes), x * 2^e with 2^e * amax in [128, 256); C a multiple of 16.

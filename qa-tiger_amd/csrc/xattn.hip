@@ -31,6 +31,7 @@ struct XAttnArgs {
     const float* dctx; const float* dasum; const float* ctx_in;
     float* du; float* dx;
     float* dx_amax;          // nullable: max|dx| record (64 floats), measured while dx is written (the out-projection's dY scale)
+    float* du_amax;          // nullable: max|du| record (the head-batched W_k GEMMs' dY scale)
 };
 
 __device__ inline float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -271,6 +272,7 @@ template <int NV>
 __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
     if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     float xmax = 0.f;                                               // max |dx| written by this thread (dx_amax)
+    float umax = 0.f;                                               // max |du| written by this thread (du_amax)
     constexpr int QB = 2, GQ = 16;        // (query, head) vectors per pass
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,9 +365,11 @@ __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
 #pragma unroll
             for (int t = 0; t < NV; ++t) {
                 const int c4 = lane + t * 64;
-                if (c4 < nv)
-                    *reinterpret_cast<float4*>(p.du + urow[b] * D + c4 * 4) =
-                        make_float4(acc[b][t].x * p.scale, acc[b][t].y * p.scale, acc[b][t].z * p.scale, acc[b][t].w * p.scale);
+                if (c4 < nv) {
+                    const float4 v = make_float4(acc[b][t].x * p.scale, acc[b][t].y * p.scale, acc[b][t].z * p.scale, acc[b][t].w * p.scale);
+                    umax = fmaxf(fmaxf(umax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    *reinterpret_cast<float4*>(p.du + urow[b] * D + c4 * 4) = v;
+                }
             }
         }
         __syncthreads();                                            // Ad / Ds / Us / Gs of this pass complete
@@ -452,6 +456,11 @@ __global__ __launch_bounds__(XA_NT, 4) void qt_xattn_bwd_kernel(XAttnArgs p) {
         if ((threadIdx.x & 63) == 0 && (xmax > 0.f || xmax != xmax))
             atomicMax(reinterpret_cast<unsigned*>(p.dx_amax) + ((blockIdx.x + (threadIdx.x >> 6)) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, xmax));
     }
+    if (p.du_amax) {
+        umax = qt_wave_max(umax);
+        if ((threadIdx.x & 63) == 0 && (umax > 0.f || umax != umax))
+            atomicMax(reinterpret_cast<unsigned*>(p.du_amax) + ((blockIdx.x + (threadIdx.x >> 6)) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, umax));
+    }
 }
 
 static int xattn_check(const char* who, int n_items, int H, int Lq, int Lk, int D) {
@@ -498,7 +507,7 @@ extern "C" int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, 
 extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, const float* x,
                             const float* ctx, const float* lse, const float* asum, const float* dctx, const float* dasum,
                             int n_items, int H, int Lq, int Lk, int D, float scale, float drop_p, unsigned long long seed,
-                            float* du, float* dx, float* dx_amax) {
+                            float* du, float* dx, float* dx_amax, float* du_amax) {
     if (int rc = xattn_check("qt_xattn_bwd", n_items, H, Lq, Lk, D)) return rc;
     QT_CHECK_ARG(u && x && ctx && lse && asum && dctx && du && dx, "qt_xattn_bwd: null pointer");
     QT_CHECK_ARG(qt_aligned16(u) && qt_aligned16(x) && qt_aligned16(ctx) && qt_aligned16(dctx) && qt_aligned16(du) && qt_aligned16(dx),
@@ -506,7 +515,7 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     XAttnArgs a; memset(&a, 0, sizeof(a));
     a.u = u; a.x = x; a.ctx_in = ctx; a.lse = (float*)lse; a.asum = (float*)asum; a.dctx = dctx; a.dasum = dasum;
     a.u_is = u_is; a.u_rs = u_rs; a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
-    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr; a.du = du; a.dx = dx; a.dx_amax = dx_amax;
+    a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr; a.du = du; a.dx = dx; a.dx_amax = dx_amax; a.du_amax = du_amax;
     const int NQ = Lq * H;
     a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
     size_t lds = 0;

@@ -293,12 +293,27 @@ def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, 
     return SplitImage(img, R, Cc, amax)
 
 
+def tag_amax(t: Tensor, rec: Tensor) -> None:
+    """Attach a producer-measured max|x| record to the tensor OBJECT autograd will hand to the consumer.  The tag remembers the
+    tensor's version counter: when autograd sums several gradients it may add into the first one in place (same object, larger
+    values) — the bumped version makes the tag void and the consumer measures again."""
+    t._qt_amax = (rec, t._version)
+
+
+def amax_tag(t: Tensor) -> Optional[Tensor]:
+    tag = getattr(t, '_qt_amax', None)
+    if tag is None or tag[1] != t._version:
+        return None
+    return tag[0]
+
+
 def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: bool = False, out: Optional[Tensor] = None,
             bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: int = 0,
             mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
-            accumulate: bool = False, alpha: float = 1.0, split_k: int = 0) -> Optional[Tensor]:
+            accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, c_amax: Optional[Tensor] = None) -> Optional[Tensor]:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)) on split images; returns None (out untouched) when the shape does not fit
-    the kernel (the caller then uses `gemm` on the fp32 tensors)."""
+    the kernel (the caller then uses `gemm` on the fp32 tensors).
+    c_amax: a zeroed max|x| record; when the launch could fill it (no split-K atomics) the returned tensor carries it as `_qt_amax`."""
     M, K = (a.cols, a.rows) if a_kslow else (a.rows, a.cols)
     N, Kb = (b.cols, b.rows) if b_kslow else (b.rows, b.cols)
     if K != Kb:
@@ -318,12 +333,15 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
         _ptr(a.data), 4 * a.cols, _ptr(a.amax), _ptr(b.data), 4 * b.cols, _ptr(b.amax),
         _ptr(out), _ld(out), _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
-        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k)))
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), _ptr(c_amax)))
     if rc == -4:
         if timer is not None:
             timer.records.pop()
         return None
-    _lib.check(rc, 'qt_gemm_ps')
+    if rc != 2:
+        _lib.check(rc, 'qt_gemm_ps')
+        if c_amax is not None:
+            tag_amax(out, c_amax)
     return out
 
 
@@ -398,7 +416,7 @@ def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int, want_ama
                                   C.c_ulonglong(seed), _ptr(out), _ld(out), g.shape[0], g.shape[1], _ptr(am))
     _lib.check(rc, 'qt_mask_grad')
     if am is not None:
-        out._qt_amax = am
+        tag_amax(out, am)
     return out
 
 
@@ -556,7 +574,7 @@ def grad_amax(dy: Tensor, g2: Optional[Tensor] = None) -> Optional[Tensor]:
     A producer that has already measured it tags the tensor (`dy._qt_amax`); otherwise one streaming pass (qt_amax_f32)."""
     if precision['bwd'] != 'f16x3':
         return None
-    tag = getattr(dy, '_qt_amax', None)
+    tag = amax_tag(dy)
     if tag is not None:
         return tag
     return amax_of(dy if g2 is None else g2)
@@ -622,15 +640,22 @@ class LinearFn(torch.autograd.Function):
             wimg = ctx.wimg
             ximg = SplitImage(x2, x2.shape[0], x2.shape[1], None)
             if ctx.needs_input_grad[0]:
+                # max|dX| is measured by the epilogue that stores it and rides on the tensor autograd hands to dX's consumer
+                cam = new_amax(g.device)
                 if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], k_in):
-                    if gemm_ps(gimg, wimg, b_kslow=True, out=link.buf, accumulate=True) is None:
+                    acc = gemm_ps(gimg, wimg, b_kslow=True, out=link.buf, accumulate=True, c_amax=cam)
+                    if acc is None:
                         raise _lib.QTError('qt_gemm_ps refused a dX shape its forward accepted')
-                    link.buf = None                     # dx stays None
+                    if link.res is not None and amax_tag(acc) is not None:
+                        tag_amax(link.res, cam)         # dx stays None: the sum lives in the residual gradient
+                    link.buf = link.res = None
                 else:
-                    dx = gemm_ps(gimg, wimg, b_kslow=True)
-                    if dx is None:
+                    dx2 = gemm_ps(gimg, wimg, b_kslow=True, c_amax=cam)
+                    if dx2 is None:
                         raise _lib.QTError('qt_gemm_ps refused a dX shape its forward accepted')
-                    dx = dx.reshape(shape)
+                    dx = dx2.reshape(shape)
+                    if amax_tag(dx2) is not None:
+                        tag_amax(dx, cam)
             if ctx.needs_input_grad[1]:
                 wgv = _claim_grad_view(w_param)
                 dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:])
@@ -646,7 +671,7 @@ class LinearFn(torch.autograd.Function):
                     cam = new_amax(g.device) if gam is not None else None
                     gemm(g, weight, trans_b=False, mode=precision['bwd'], out=link.buf, accumulate=True, a_amax=gam, b_amax=ctx.wam, c_amax=cam)
                     if cam is not None and link.res is not None:
-                        link.res._qt_amax = cam
+                        tag_amax(link.res, cam)
                     link.buf = link.res = None
                 else:
                     dx = gemm(g, weight, trans_b=False, mode=precision['bwd'], a_amax=gam, b_amax=ctx.wam).reshape(shape)
@@ -764,7 +789,7 @@ class AttentionFn(torch.autograd.Function):
         _lib.check(rc, 'qt_attn_bwd')
         dq_out = dqb.reshape(qshape)
         if gam is not None:
-            dq_out._qt_amax = gam                      # the in-projection's backward GEMMs scale dY by it (grad_amax)
+            tag_amax(dq_out, gam)                      # the in-projection's backward GEMMs scale dY by it (grad_amax)
         return dq_out, (None if packed else dkb.reshape(kvshape)), None, None, None
 
 
@@ -799,8 +824,9 @@ class HeadExpandFn(torch.autograd.Function):
         H = ctx.H
         M, E = q2.shape
         D, dh = w2.shape[1], E // H
+        du_in = du
         du = as2d(du.contiguous())
-        gam = grad_amax(du)
+        gam = grad_amax(du_in, du) if du_in.is_contiguous() else grad_amax(du)       # FoldAttnFn.backward tags dU with its max
         dq = dw = None
         if ctx.needs_input_grad[0]:
             dq = torch.empty_like(q2)
@@ -833,8 +859,9 @@ class HeadContractFn(torch.autograd.Function):
         H = ctx_.H
         D = w2.shape[1]
         dh = w2.shape[0] // H
+        do_in = do
         do = as2d(do.contiguous())
-        gam = grad_amax(do)
+        gam = grad_amax(do_in, do) if do_in.is_contiguous() else grad_amax(do)
         dc = dw = None
         if ctx_.needs_input_grad[0]:
             dc = torch.empty_like(c2)
@@ -876,15 +903,19 @@ class FoldAttnFn(torch.autograd.Function):
         dasum = None if dasum is None else dasum.contiguous()
         du, dx = torch.empty_like(u2), torch.empty_like(x2)
         xam = new_amax(x2.device) if precision['bwd'] == 'f16x3' else None
+        uam = new_amax(x2.device) if precision['bwd'] == 'f16x3' else None
         nbytes = 4.0 * D * (4 * u2.shape[0] * H + 2 * n_items * Lk)
         rc = _launch('attn_bwd', nbytes, ('fold', n_items, Lq, Lk, D), lambda: _lib.load().qt_xattn_bwd(
             _stream(), _ptr(u2), u_is, u_rs, _ptr(x2), _ptr(c), _ptr(lse), _ptr(asum), _ptr(dc), _ptr(dasum),
-            n_items, H, Lq, Lk, D, float(scale), float(drop_p), C.c_ulonglong(seed), _ptr(du), _ptr(dx), _ptr(xam)))
+            n_items, H, Lq, Lk, D, float(scale), float(drop_p), C.c_ulonglong(seed), _ptr(du), _ptr(dx), _ptr(xam), _ptr(uam)))
         _lib.check(rc, 'qt_xattn_bwd')
         dx_out = dx.reshape(xshape)
         if xam is not None:
-            dx_out._qt_amax = xam                      # max|dx| measured while dx was written: the producer layer's dY scale
-        return du.reshape(ushape), dx_out, None, None, None, None, None, None, None, None, None
+            tag_amax(dx_out, xam)                      # max|dx| measured while dx was written: the producer layer's dY scale
+        du_out = du.reshape(ushape)
+        if uam is not None:
+            tag_amax(du_out, uam)                      # the head-batched W_k GEMMs (HeadExpandFn.backward) scale dU by it
+        return du_out, dx_out, None, None, None, None, None, None, None, None, None
 
 
 def folded_attention(q: Tensor, x: Tensor, mha, n_items: int, Lq: int, Lk: int, u_is: int, u_rs: int,
@@ -978,7 +1009,7 @@ class AddLayerNormFn(torch.autograd.Function):
         outs = [d.reshape(shp) if d is not None else None for d, shp in zip(dxs, shapes)]
         for o_, a_ in zip(outs, ams):
             if o_ is not None and a_ is not None:
-                o_._qt_amax = a_
+                tag_amax(o_, a_)
         return (dgamma, dbeta, None, None, None, None, None, *outs)
 
 

@@ -109,9 +109,11 @@ class AVQCrossAttn(nn.Module):
         kv = ops.linear(query, *_mha_proj(self.qst_attn, 'kv'))
         qst_spec, qst_seed = AttnSpec(2 * B, B, 0, H, T, L, D, 0, 0, D), nxt()
         o_q = ops.attention(q, kv, qst_spec, p, qst_seed)
-        a_s = ops.linear(o_s, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias).reshape(2 * B, T, D)
-        a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias).reshape(2 * B, T, D)
-        a_q = ops.linear(o_q, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias).reshape(2 * B, T, D)
+        # (kept as [2B*T, D]: add_layer_norm takes any shapes with the same rows; a reshape node between the two would strip the
+        # max|dY| tag the LayerNorm backward puts on these layers' gradients)
+        a_s = ops.linear(o_s, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias)
+        a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias)
+        a_q = ops.linear(o_q, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias)
         x = ops.add_layer_norm([x, a_s, a_c, a_q], self.norm1.weight, self.norm1.bias,
                                drops=[False, True, True, True], drop_p=p)
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p, seed=nxt())

@@ -123,6 +123,31 @@ def test_gemm_ps_both_tile_heights(ops, wmt, monkeypatch):
     assert torch.equal(d1 == 0, d2 == 0) and rel(d1, d2) < 1e-5
 
 
+def test_gemm_ps_records_max_of_what_it_stores(ops):
+    """c_amax: the epilogue folds max|C| of the values AS STORED (bias, ReLU, accumulate included) into the caller's record; a
+    split-K launch cannot (partial sums) and leaves the tensor untagged."""
+    x, w = rnd(1100, 256, seed=21), rnd(320, 256, seed=22)
+    ix, iw = ops.split_image(x.to(DEV)), ops.split_image(w.to(DEV))
+    for kw in (dict(), dict(bias=rnd(320, seed=23).to(DEV), relu=1), dict(b_kslow=True)):
+        b = ops.split_image(rnd(256, 320, seed=24).to(DEV)) if kw.get('b_kslow') else iw
+        rec = ops.new_amax(DEV)
+        out = ops.gemm_ps(ix, b, c_amax=rec, split_k=1, **kw)
+        assert ops.amax_tag(out) is rec and float(rec.max()) == float(out.abs().max())
+    acc = rnd(1100, 320, seed=25).to(DEV) * 100
+    rec = ops.new_amax(DEV)
+    out = ops.gemm_ps(ix, iw, out=acc, accumulate=True, c_amax=rec, split_k=1)
+    assert float(rec.max()) == float(acc.abs().max())
+    rec = ops.new_amax(DEV)
+    out = ops.gemm_ps(ix, iw, c_amax=rec, split_k=2)
+    assert ops.amax_tag(out) is None and float(rec.max()) == 0.0
+    # a tag dies with an in-place update of the tensor (autograd adds gradients in place)
+    t = torch.ones(4, 4, device=DEV)
+    ops.tag_amax(t, rec)
+    assert ops.amax_tag(t) is rec
+    t.add_(1.0)
+    assert ops.amax_tag(t) is None
+
+
 @pytest.mark.parametrize('sa,sb', [(1e-7, 1.0), (1e5, 1e-4), (3e-9, 2e-5), (1e3, 1e3)])
 def test_gemm_ps_scaled_operands_any_magnitude(ops, sa, sb):
     """Gradient-like (1e-7..1e-9), tiny-weight (1e-4) and huge-activation (1e5) operands: with the per-tensor power-of-two scale
