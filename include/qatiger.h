@@ -184,6 +184,11 @@ int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C, float* am
 /* the same for n_segments tensors of one flat buffer in one launch: amax[s] = max |flat[offsets[s] .. offsets[s] + counts[s])|
  * (offsets / counts: device int64 arrays; amax: n_segments records of 64 floats).  Every parameter's scale after an optimizer step. */
 int qt_amax_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments, float* amax);
+/* Split images of n_segments tensors of one flat buffer in one launch (all weight matrices after an optimizer step): the image of
+ * flat[offsets[s] .. + counts[s]) is written to the same element range of `img` (128-byte aligned, as large as `flat`), scaled by
+ * record amax[s] (qt_amax_segments).  Segments whose start or length is not a multiple of 32 elements are skipped. */
+int qt_split_f16_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments,
+                          const float* amax, void* img);
 /* fp32 [R, C] -> split image: per row and per block of 32 columns one 128-byte line [32 x fp16 hi | 32 x fp16 lo] with
  * hi = fp16(s x), lo = fp16(s x - hi); s = 2^e chosen from *amax (nullable: s = 1) so that s * amax lies in [2^13, 2^14).
  * img: R rows of ld_img_bytes (multiple of 128, >= 4 C).  colsum (nullable): colsum[c] = sum_r x[r, c], the bias gradient of a

@@ -731,6 +731,39 @@ extern "C" int qt_amax_segments(void* stream, const float* flat, const long* off
     return QT_OK;
 }
 
+// Split images of n_segments tensors of one flat buffer in one launch (every weight matrix after an optimizer step): segment s is
+// flat[off[s] .. off[s] + cnt[s]) and its image occupies the SAME element range of `img` (an image has the size of its tensor);
+// each is scaled by its own record amax[s].  Segments that cannot be an image (start or length not a multiple of 32 elements:
+// biases, LayerNorm vectors) are skipped.
+__global__ __launch_bounds__(256) void qt_split_segments_kernel(const float* __restrict__ flat, const long* __restrict__ off, const long* __restrict__ cnt,
+                                                                const float* __restrict__ amax, char* __restrict__ img) {
+    const int sgm = blockIdx.y;
+    const long o = off[sgm], n = cnt[sgm];
+    if ((o & 31) || (n & 31)) return;                                 // block-uniform
+    const float s = qt_plane_scale(qt_amax_read(amax + (long)sgm * QT_AMAX_SLOTS));
+    const float* x = flat + o;
+    char* im = img + o * 4;
+    const long n8 = n >> 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n8; idx += (long)gridDim.x * 256) {
+        const float4 a = *reinterpret_cast<const float4*>(x + idx * 8);
+        const float4 b = *reinterpret_cast<const float4*>(x + idx * 8 + 4);
+        uint4 hi, lo;
+        qt_split8(a, b, s, hi, lo);
+        char* line = im + (idx >> 2) * 128 + (idx & 3) * 16;
+        *reinterpret_cast<uint4*>(line) = hi;
+        *reinterpret_cast<uint4*>(line + 64) = lo;
+    }
+}
+
+extern "C" int qt_split_f16_segments(void* stream, const float* flat, const long* offsets, const long* counts, int n_segments,
+                                     const float* amax, void* img) {
+    QT_CHECK_ARG(flat && offsets && counts && amax && img && n_segments > 0, "qt_split_f16_segments: bad arguments");
+    QT_CHECK_ARG(n_segments <= 65535 && qt_aligned16(flat) && ((size_t)img & 127) == 0, "qt_split_f16_segments: segments / alignment");
+    hipLaunchKernelGGL(qt_split_segments_kernel, dim3(64, (unsigned)n_segments), dim3(256), 0, (hipStream_t)stream, flat, offsets, counts, amax, (char*)img);
+    QT_CHECK_LAUNCH("qt_split_f16_segments");
+    return QT_OK;
+}
+
 // any row length / alignment (the head's [B, 42] logit gradients, ...)
 __global__ __launch_bounds__(256) void qt_amax_scalar_kernel(const float* __restrict__ x, long ldx, long R, int C, float* __restrict__ amax) {
     const long total = R * C;

@@ -307,6 +307,27 @@ def amax_tag(t: Tensor) -> Optional[Tensor]:
     return tag[0]
 
 
+class _ReshapeFn(torch.autograd.Function):
+    """x.reshape(shape) whose backward keeps the max|dY| tag on the gradient (torch's own view node hands on a new, untagged tensor)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, shape):
+        ctx.in_shape = x.shape
+        return x.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g2 = g.reshape(ctx.in_shape)
+        rec = amax_tag(g)
+        if rec is not None and g2 is not g:
+            tag_amax(g2, rec)
+        return g2, None
+
+
+def reshape(x: Tensor, shape) -> Tensor:
+    return _ReshapeFn.apply(x, tuple(shape)) if x.requires_grad and torch.is_grad_enabled() else x.reshape(shape)
+
+
 def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: bool = False, out: Optional[Tensor] = None,
             bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: int = 0,
             mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
@@ -471,13 +492,22 @@ def weight_image(weight: Tensor) -> Optional[SplitImage]:
     rows_b, cols = base.shape
     if cols % 32 or weight.shape[1] != cols:
         return None
-    key = (base._version, weights_epoch, base.data_ptr())
-    cached = getattr(base, '_qt_wimg', None)
-    if cached is None or cached[0] != key:
-        with torch.no_grad():
-            cached = (key, split_image(base.detach(), scaled=True))
-        base._qt_wimg = cached
-    img = cached[1]
+    flat = getattr(base, '_qt_flat', None)
+    if flat is not None and base.data_ptr() == flat.flat.data_ptr() + 4 * base._qt_flat_off:
+        # train.FlatParams: every weight's image is refreshed by ONE launch per optimizer step and lives in flat.img at the weight's own offset
+        if flat.img_epoch != weights_epoch or getattr(base, '_qt_img_ver', -1) != base._version:
+            with torch.no_grad():
+                flat.refresh_images()
+        o = base._qt_flat_off
+        img = SplitImage(flat.img[o:o + base.numel()].view(rows_b, cols), rows_b, cols, base._qt_amax_view)
+    else:
+        key = (base._version, weights_epoch, base.data_ptr())
+        cached = getattr(base, '_qt_wimg', None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, split_image(base.detach(), scaled=True))
+            base._qt_wimg = cached
+        img = cached[1]
     r0 = (weight.storage_offset() - base.storage_offset()) // cols
     if weight.shape[0] == rows_b and r0 == 0:
         return img

@@ -287,7 +287,7 @@ class PatchSelecter(nn.Module):
         BT, H = B * T, self.nhead
         p = self.dropout.p if self.training else 0.0
         nxt = ops.seeds.next
-        pp = patch.reshape(BT * P, D)
+        pp = ops.reshape(patch, (BT * P, D))                               # (keeps the max|d_pp| tag of the linked dX GEMM for patch_proj's backward)
         # per-frame self-attention over the P patch tokens, residual, no norm (modules.py:688)
         link = ops.GradLink()                                              # d(pp) = residual gradient + in-projection dX, summed inside the dX GEMM
         qkv = ops.linear(pp, *_mha_proj(self.slf_attn, 'qkv'), link=link)

@@ -27,7 +27,7 @@ from torch import Tensor
 
 from . import ops
 
-_ALIGN = 4          # elements: every parameter view starts on a 16-byte boundary
+_ALIGN = 32         # elements: every parameter view starts on a 128-byte boundary (one line of a split image, ops.weight_image)
 
 
 class CrossEntropyLoss(nn.Module):
@@ -63,11 +63,15 @@ class FlatParams:
         self._seg_off = torch.tensor(self.offsets, dtype=torch.int64, device=dev)
         self._seg_cnt = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self.amax_epoch = None
+        # split images of all weight matrices (the operands of the pre-split GEMMs), refreshed in one launch per optimizer step; made on first use
+        self.img: Optional[torch.Tensor] = None
+        self.img_epoch = None
         for i, (p, gv) in enumerate(zip(self.params, self.grad_views)):
             p._qt_gv = gv                          # ops.LinearFn writes dW / db straight into the flat gradient buffer
             if dev.type == 'cuda':
                 p._qt_amax_view = self.amax[i]
                 p._qt_flat = self
+                p._qt_flat_off = self.offsets[i]
 
     def numel(self) -> int:
         return sum(p.numel() for p in self.params)
@@ -80,6 +84,19 @@ class FlatParams:
         self.amax_epoch = ops.weights_epoch
         for p in self.params:
             p._qt_amax_ver = p._version             # (a load_state_dict / copy_ into the parameters bumps the version: re-measure)
+
+    def refresh_images(self) -> None:
+        """max|w| and the split image of every weight matrix: two launches per optimizer step (qt_amax_segments, qt_split_f16_segments)."""
+        if self.amax_epoch != ops.weights_epoch or any(getattr(p, '_qt_amax_ver', -1) != p._version for p in self.params):
+            self.refresh_amax()
+        if self.img is None:
+            self.img = torch.empty_like(self.flat)
+        lib = ops._lib.load()
+        ops._lib.check(lib.qt_split_f16_segments(ops._stream(), ops._ptr(self.flat), ops._ptr(self._seg_off), ops._ptr(self._seg_cnt),
+                                                 len(self.params), ops._ptr(self.amax), ops._ptr(self.img)), 'qt_split_f16_segments')
+        self.img_epoch = ops.weights_epoch
+        for p in self.params:
+            p._qt_img_ver = p._version
 
     def check(self) -> None:
         """The parameters must still BE views of the flat buffer.  `model.to(...)`, `model.float()`, `load_state_dict(...,
