@@ -237,9 +237,11 @@ AMAX_SLOTS = 64          # a max|x| record is 64 floats; its value is their maxi
 
 
 class _AmaxPool:
-    """Zeroed max|x| records without a launch per record: 2 x 256 records, the half about to be handed out is zeroed by ONE kernel
-    (records of the other half — a backward pass uses a few dozen — stay readable until the cursor comes round again)."""
-    HALF = 256
+    """Zeroed max|x| records without a launch per record: 2 x 1024 records, the half about to be handed out is zeroed by ONE kernel.
+    A record stays readable for at least 1024 further takes — enough for a producer -> consumer hand-over inside one backward pass
+    (a train step takes ~250), NOT for anything cached: a weight's maximum, an activation's maximum saved for the backward and
+    every other record that outlives the pass is allocated on its own (`amax_of(..., keep=True)`)."""
+    HALF = 1024
 
     def __init__(self):
         self.buf = None
@@ -265,18 +267,19 @@ def new_amax(device) -> Tensor:
     return _amax_pool.take(device)
 
 
-def amax_of(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """max |x| as a device record of 64 floats (no host sync; take `.max()` to read it); `out` folds into an earlier one."""
+def amax_of(x: Tensor, out: Optional[Tensor] = None, keep: bool = False) -> Tensor:
+    """max |x| as a device record of 64 floats (no host sync; take `.max()` to read it); `out` folds into an earlier one.
+    keep=True: the record is cached by the caller beyond the current pass, so it gets memory of its own instead of a pooled slot."""
     x = as2d(x)
     _dev(x)
     if out is None:
-        out = _amax_pool.take(x.device)
+        out = torch.zeros(AMAX_SLOTS, device=x.device, dtype=torch.float32) if keep else _amax_pool.take(x.device)
     _lib.check(_launch('split', 4.0 * x.numel(), ('amax',) + tuple(x.shape), lambda: _lib.load().qt_amax_f32(
         _stream(), _ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(out), 0)), 'qt_amax_f32')
     return out
 
 
-def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, colsum: Optional[Tensor] = None) -> SplitImage:
+def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, colsum: Optional[Tensor] = None, keep: bool = False) -> SplitImage:
     """fp32 [rows, cols] -> SplitImage.  scaled=True measures max|x| first (one extra read of x) and scales the parts into
     fp16's normal range; pass `amax` when a producer has already measured it."""
     x = as2d(x)
@@ -285,7 +288,7 @@ def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, 
     if Cc % 32:
         raise _lib.QTError(f'split_image: {Cc} columns is not a multiple of 32')
     if scaled and amax is None:
-        amax = amax_of(x)
+        amax = amax_of(x, keep=keep)
     img = torch.empty((R, Cc), device=x.device, dtype=torch.float32)
     rc = _launch('split', 8.0 * R * Cc, (R, Cc), lambda: _lib.load().qt_split_f16(
         _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), 4 * Cc, _ptr(colsum)))
@@ -300,8 +303,11 @@ def tag_amax(t: Tensor, rec: Tensor) -> None:
     t._qt_amax = (rec, t._version)
 
 
+use_amax_tags = True     # False: every consumer measures max|dY| itself (A/B and debugging of the tag protocol)
+
+
 def amax_tag(t: Tensor) -> Optional[Tensor]:
-    tag = getattr(t, '_qt_amax', None)
+    tag = getattr(t, '_qt_amax', None) if use_amax_tags else None
     if tag is None or tag[1] != t._version:
         return None
     return tag[0]
@@ -366,7 +372,7 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
     return out
 
 
-def quant_fp8(x: Tensor, amax: Optional[Tensor] = None) -> SplitImage:
+def quant_fp8(x: Tensor, amax: Optional[Tensor] = None, keep: bool = False) -> SplitImage:
     """fp32 [rows, cols] -> e4m3 image (one byte per element, per-tensor power-of-two scale from max|x|): BASELINE configs[4]."""
     x = as2d(x)
     _dev(x)
@@ -374,7 +380,7 @@ def quant_fp8(x: Tensor, amax: Optional[Tensor] = None) -> SplitImage:
     if Cc % 128:
         raise _lib.QTError(f'quant_fp8: {Cc} columns is not a multiple of 128')
     if amax is None:
-        amax = amax_of(x)
+        amax = amax_of(x, keep=keep)
     img = torch.empty((R, Cc), device=x.device, dtype=torch.uint8)
     _lib.check(_launch('split', 5.0 * R * Cc, ('fp8', R, Cc), lambda: _lib.load().qt_quant_fp8(
         _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), Cc)), 'qt_quant_fp8')
@@ -505,7 +511,7 @@ def weight_image(weight: Tensor) -> Optional[SplitImage]:
         cached = getattr(base, '_qt_wimg', None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                cached = (key, split_image(base.detach(), scaled=True))
+                cached = (key, split_image(base.detach(), scaled=True, keep=True))
             base._qt_wimg = cached
         img = cached[1]
     r0 = (weight.storage_offset() - base.storage_offset()) // cols
@@ -526,7 +532,7 @@ def weight_image_fp8(weight: Tensor) -> Optional[SplitImage]:
     cached = getattr(base, '_qt_wimg8', None)
     if cached is None or cached[0] != key:
         with torch.no_grad():
-            cached = (key, quant_fp8(base.detach()))
+            cached = (key, quant_fp8(base.detach(), keep=True))
         base._qt_wimg8 = cached
     img = cached[1]
     r0 = (weight.storage_offset() - base.storage_offset()) // cols
@@ -540,7 +546,7 @@ def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
     if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape \
             and not torch.cuda.is_current_stream_capturing():
         return cached[1]
-    img = quant_fp8(x2.detach())
+    img = quant_fp8(x2.detach(), keep=True)        # cached on the tensor object
     x._qt_img8 = ((x._version, x.data_ptr()), img)
     return img
 
@@ -582,7 +588,7 @@ def weight_amax(weight: Tensor) -> Optional[Tensor]:
     cached = getattr(base, '_qt_wamax', None)
     if cached is None or cached[0] != key:
         with torch.no_grad():
-            cached = (key, amax_of(base.detach().reshape(-1, base.shape[-1]) if base.dim() > 1 else base.detach().reshape(1, -1)))
+            cached = (key, amax_of(base.detach().reshape(-1, base.shape[-1]) if base.dim() > 1 else base.detach().reshape(1, -1), keep=True))
         base._qt_wamax = cached
     return cached[1]
 
@@ -594,7 +600,7 @@ def act_amax(x: Tensor, x2: Tensor) -> Optional[Tensor]:
     cached = getattr(x, '_qt_xamax', None)
     if cached is not None and cached[0] == (x._version, x.data_ptr()) and not torch.cuda.is_current_stream_capturing():
         return cached[1]
-    am = amax_of(x2.detach())
+    am = amax_of(x2.detach(), keep=True)           # read again by the backward's dW GEMM: not a pooled slot
     x._qt_xamax = ((x._version, x.data_ptr()), am)
     return am
 

@@ -440,6 +440,7 @@ class GraphedForward:
                 model(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        ops._amax_pool.cur = 0                          # (any pooled max|x| record the forward takes is zeroed inside the capture)
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = model(self.static_in)
 

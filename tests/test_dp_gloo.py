@@ -52,8 +52,9 @@ def _worker(rank, world, port, bucket_bytes, q):
                                       torch.nn.Linear(16, 4))
         ref_net.load_state_dict(net.state_dict())
         ((ref_net(x_all) - y_all) ** 2).sum().backward()
-        ref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in ref_net.parameters()]
-                        + [torch.zeros(8)])
+        al = train._ALIGN                                       # every parameter starts on an aligned offset of the flat buffer; padding stays zero
+        ref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % al)) for p in ref_net.parameters()]
+                        + [torch.zeros(5 + (-5) % al)])
         ok = all(torch.allclose(o, ref, atol=1e-5, rtol=1e-5) for o in out)
         ok = ok and all(p.grad is v for p, v in zip(params[:-1], flat.grad_views))     # grads live in the flat buffer
         q.put((rank, ok, float((out[-1] - ref).abs().max())))

@@ -305,6 +305,35 @@ def test_training_soak_at_real_dims(qt, synth):
     assert eng.optim.step_count == 40
 
 
+def test_repeated_backward_with_unchanged_weights_is_stable(qt, synth):
+    """Weights' max|w| records and split images are cached while the weights do not change (evaluation, gradient accumulation,
+    a stock optimizer stepping every n-th batch).  The records of one backward pass come from a recycled pool; a cached record
+    must not live there (regression: after ~500 pooled records the cached weight scales were overwritten and every gradient
+    was off by 4e-3).  Twelve fwd+bwd passes cycle the pool more than once: the last gradients must equal the first."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 16})
+    model = qt.QA_TIGER(**cfg.model_kwargs())
+    model.load_state_dict(synth.make_state_dict(cfg, 5), strict=True)
+    model = model.to(DEV).eval()
+    inp = to_dev(synth.make_inputs(cfg, 5))
+    keep_half = qt.ops._AmaxPool.HALF
+    qt.ops._AmaxPool.HALF = 64                                   # cycle quickly
+    qt.ops._amax_pool.buf = None
+    try:
+        first = None
+        for it in range(12):
+            model.zero_grad(set_to_none=True)
+            qt.CrossEntropyLoss()(model(inp)['out'], inp['label']).backward()
+            g = torch.cat([p.grad.flatten() for p in model.parameters()])
+            if first is None:
+                first = g.clone()
+        d = float((g - first).norm() / first.norm())
+        print(f'gradient drift over 12 passes with cached weight images: {d:.2e}')
+        assert d < 2e-5
+    finally:
+        qt.ops._AmaxPool.HALF = keep_half
+        qt.ops._amax_pool.buf = None
+
+
 def test_range_guard_large_activations_and_tiny_weights(qt, synth, oracle):
     """fp16-split GEMMs outside fp16's comfortable range: features of magnitude ~1e5 and projection weights of
     ~1e-4.  Weight operands are always scaled by max|w| (free: one launch per optimizer step), so tiny weights cost nothing.
