@@ -880,7 +880,10 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
             for (long s = fixed_split ? split_k : 1; s <= (fixed_split ? split_k : maxs); ++s) {
                 const long rounds = (tl * s + slots - 1) / slots;
                 const long ksteps = ((K + s - 1) / s + KS - 1) / KS;
-                const long cost = rounds * (ksteps + ovh) * (cand == 4 ? 100 : 79);      // 79 = 75 x 1.05
+                long cost = rounds * (ksteps + ovh) * (cand == 4 ? 100 : 79);      // 79 = 75 x 1.05
+                // split-K pays for its fp32 atomics at the L2's rate (measured: ~270 per ns for the whole chip = 513e3 per K-step time
+                // of 1.9 us) plus the zeroing launch and the drain (~20 us): tools/sweep_splitk.py
+                if (s > 1) cost += (long)(((double)s * M * N / 513e3 + 10.0) * 100.0);
                 if (best < 0 || cost < best) { best = cost; best_s = (int)s; wmt = cand; }
             }
         }
