@@ -192,9 +192,10 @@ int qt_split_f16_segments(void* stream, const float* flat, const long* offsets, 
 /* fp32 [R, C] -> split image: per row and per block of 32 columns one 128-byte line [32 x fp16 hi | 32 x fp16 lo] with
  * hi = fp16(s x), lo = fp16(s x - hi); s = 2^e chosen from *amax (nullable: s = 1) so that s * amax lies in [2^13, 2^14).
  * img: R rows of ld_img_bytes (multiple of 128, >= 4 C).  colsum (nullable): colsum[c] = sum_r x[r, c], the bias gradient of a
- * Linear layer whose dY is being split for its dX / dW GEMMs (overwritten). */
+ * Linear layer whose dY is being split for its dX / dW GEMMs (overwritten; colsum_accumulate != 0: added to what is there, e.g. the
+ * parameter's slice of a gradient buffer the caller has zeroed once for the whole step). */
 int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const float* amax, void* img, long ld_img_bytes,
-                 float* colsum);
+                 float* colsum, int colsum_accumulate);
 /* C[M,N] = epilogue(alpha / (s_a s_b) * op(A) op(B)) with the epilogue of qt_gemm_f32, on split images streamed to LDS by LDS-DMA.
  *   a_kslow = 0: A image holds [M rows][K];  a_kslow = 1: [K rows][M]  (dW = dY^T X reads dY and X this way)
  *   b_kslow = 0: B image holds [N rows][K] (nn.Linear weight layout);  b_kslow = 1: [K rows][N]

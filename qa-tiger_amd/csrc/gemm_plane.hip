@@ -798,7 +798,7 @@ extern "C" int qt_amax_f32(void* stream, const float* x, long ldx, long R, int C
 }
 
 extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const float* amax, void* img, long ld_img_bytes,
-                            float* colsum) {
+                            float* colsum, int colsum_accumulate) {
     QT_CHECK_ARG(x && img && R > 0 && C > 0 && ldx >= C, "qt_split_f16: bad arguments");
     QT_CHECK_ARG(C % 32 == 0, "qt_split_f16: the image is made of 32-column lines (C=%d)", C);
     QT_CHECK_ARG(ldx % 4 == 0 && qt_aligned16(x) && qt_aligned16(img) && ld_img_bytes % 128 == 0 && ld_img_bytes >= 4L * C,
@@ -820,7 +820,7 @@ extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int 
         if (chunks < 1) chunks = 1;
         const int rpc = (int)((((R + chunks - 1) / chunks) + 31) / 32 * 32);
         chunks = (R + rpc - 1) / rpc;
-        hipLaunchKernelGGL(qt_zero_n_kernel, dim3((C + 255) / 256), dim3(256), 0, st, colsum, C);
+        if (!colsum_accumulate) hipLaunchKernelGGL(qt_zero_n_kernel, dim3((C + 255) / 256), dim3(256), 0, st, colsum, C);
         hipLaunchKernelGGL(qt_split_f16_colsum_kernel, dim3((unsigned)strips, (unsigned)chunks), dim3(256), 0, st, x, ldx, R, C, amax,
                            (char*)img, ld_img_bytes, rpc, colsum);
     }

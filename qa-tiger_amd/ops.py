@@ -279,7 +279,8 @@ def amax_of(x: Tensor, out: Optional[Tensor] = None, keep: bool = False) -> Tens
     return out
 
 
-def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, colsum: Optional[Tensor] = None, keep: bool = False) -> SplitImage:
+def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, colsum: Optional[Tensor] = None, keep: bool = False,
+                colsum_accumulate: bool = False) -> SplitImage:
     """fp32 [rows, cols] -> SplitImage.  scaled=True measures max|x| first (one extra read of x) and scales the parts into
     fp16's normal range; pass `amax` when a producer has already measured it."""
     x = as2d(x)
@@ -291,7 +292,7 @@ def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, 
         amax = amax_of(x, keep=keep)
     img = torch.empty((R, Cc), device=x.device, dtype=torch.float32)
     rc = _launch('split', 8.0 * R * Cc, (R, Cc), lambda: _lib.load().qt_split_f16(
-        _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), 4 * Cc, _ptr(colsum)))
+        _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), 4 * Cc, _ptr(colsum), int(colsum_accumulate)))
     _lib.check(rc, 'qt_split_f16')
     return SplitImage(img, R, Cc, amax)
 
@@ -453,17 +454,84 @@ def mask_grad(g: Tensor, y: Optional[Tensor], drop_p: float, seed: int, want_ama
 # Parameters that own a slice of the flat gradient buffer (train.FlatParams sets `_qt_gv`) get their dW / db written
 # there by the producing GEMM instead of into a temporary that a hook then copies.  Only the FIRST producer of a
 # parameter in a step may do so (a second use of a shared weight would overwrite it); GradSync.begin() clears the set.
-grad_claims = set()
+#
+# With train.GradSync driving the step (`direct_grads`): every parameter's `.grad` IS its slice of the zeroed flat buffer for the
+# whole step, a producer that claimed (a row range of) it accumulates there, reports it (`_grad_written`) and hands autograd
+# None — no AccumulateGrad clone, no hook copy, and for a row slice of a packed MHA in-projection (q | k | v blocks used by
+# different layers) no zero-padded full-size temporary either.  GradSync learns that a parameter is complete from `grad_ready_cb`.
+grad_claims = set()         # id(parameter) (whole) or (id(parameter), first row, rows) (leading-dimension slice)
 grads_prezeroed = False     # train.GradSync.begin() zeroes the flat gradient buffer with ONE launch; the first producer of a claimed
                             # parameter then ACCUMULATES into its slice (no zeroing launch per dW GEMM for split-K / bias column sums)
+direct_grads = False        # set by train.GradSync.begin() (device steps only), cleared by finish()
+grad_ready_cb = None        # callable(parameter): all rows of the parameter's gradient have been written in place
+_claimed_rows = {}          # id(parameter) -> [parameter, rows written in place so far, [(r0, r1), ...]]
+
+
+def _param_rows(t: Tensor):
+    """(parameter, first row, rows) when `t` is a FlatParams parameter or a contiguous leading-dimension slice of one."""
+    if getattr(t, '_qt_gv', None) is not None:
+        return t, 0, (t.shape[0] if t.dim() > 0 else 1)
+    base = t._base
+    # (row ranges of MATRICES only: the q | k | v blocks of a packed in-projection weight each have an in-place producer; the
+    # blocks of its bias do not all have one, and a gradient that arrives half in place, half through autograd would have to
+    # wait for the end of the backward pass before its bucket may be reduced)
+    if base is None or getattr(base, '_qt_gv', None) is None or t.dim() != 2 or base.dim() != 2 \
+            or t.shape[1:] != base.shape[1:] or t.stride() != base.stride() or not base.is_contiguous():
+        return None
+    inner = 1
+    for d in base.shape[1:]:
+        inner *= d
+    off = t.storage_offset() - base.storage_offset()
+    if off < 0 or off % inner:
+        return None
+    return base, off // inner, t.shape[0]
 
 
 def _claim_grad_view(param: Tensor):
-    gv = getattr(param, '_qt_gv', None)
-    if gv is None or id(param) in grad_claims or not gv.is_cuda:
+    """The slice of the flat gradient buffer a producer may write `param`'s gradient into, or None (not a FlatParams parameter,
+    already claimed this step — a shared weight's second use —, or an overlapping row range)."""
+    pr = _param_rows(param)
+    if pr is None:
         return None
-    grad_claims.add(id(param))
-    return gv
+    base, r0, rows = pr
+    gv = base._qt_gv
+    if not gv.is_cuda:
+        return None
+    whole = r0 == 0 and (base.dim() == 0 or rows == base.shape[0])
+    if not whole and not direct_grads:           # a row range can only be handed over in place (autograd wants the full-size gradient)
+        return None
+    ent = _claimed_rows.get(id(base))
+    if id(base) in grad_claims or (ent is not None and any(r0 < b and a < r0 + rows for a, b in ent[2])):
+        return None
+    if whole:
+        grad_claims.add(id(base))
+    if ent is None:
+        ent = _claimed_rows[id(base)] = [base, 0, []]
+    ent[2].append((r0, r0 + rows))
+    return gv if whole else gv[r0:r0 + rows]
+
+
+def _unclaim(param: Tensor) -> None:
+    pr = _param_rows(param)
+    if pr is not None:
+        base, r0, rows = pr
+        grad_claims.discard(id(base))
+        ent = _claimed_rows.get(id(base))
+        if ent is not None and (r0, r0 + rows) in ent[2]:
+            ent[2].remove((r0, r0 + rows))
+
+
+def _grad_written(param: Tensor, view: Tensor):
+    """The producer has launched the kernels that accumulate `param`'s gradient into `view` (from _claim_grad_view).
+    Returns what the autograd Function should return for it: None in the direct mode, the view otherwise."""
+    if not direct_grads:
+        return view[:]
+    base, r0, rows = _param_rows(param)
+    ent = _claimed_rows[id(base)]
+    ent[1] += rows
+    if ent[1] >= (base.shape[0] if base.dim() > 0 else 1) and grad_ready_cb is not None:
+        grad_ready_cb(base)
+    return None
 
 
 class GradLink:
@@ -668,11 +736,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.used_plane:
             # dY: one max|dY| pass, one split pass (which also sums the columns = the bias gradient); both GEMMs then stream the image
             n_out, k_in = weight.shape
+            bgv = None
             if want_db:
                 bgv = _claim_grad_view(b_param)
                 db = bgv[:] if bgv is not None else torch.empty((n_out,), device=g.device, dtype=torch.float32)
             gam = grad_amax(dy, g)                          # measured by dY's producer when it could (attention / LayerNorm / mask kernels)
-            gimg = split_image(g, scaled=gam is None, amax=gam, colsum=db)
+            gimg = split_image(g, scaled=gam is None, amax=gam, colsum=db, colsum_accumulate=bgv is not None and grads_prezeroed)
+            if bgv is not None:
+                db = _grad_written(b_param, bgv)
             wimg = ctx.wimg
             ximg = SplitImage(x2, x2.shape[0], x2.shape[1], None)
             if ctx.needs_input_grad[0]:
@@ -694,11 +765,13 @@ class LinearFn(torch.autograd.Function):
                         tag_amax(dx, cam)
             if ctx.needs_input_grad[1]:
                 wgv = _claim_grad_view(w_param)
-                dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:])
+                # a claimed slice of the zeroed flat gradient buffer is accumulated into: no zeroing launch in front of a split-K GEMM
+                dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:],
+                             accumulate=wgv is not None and grads_prezeroed)
                 if dw is None:
                     raise _lib.QTError('qt_gemm_ps refused a dW shape its forward accepted')
                 if wgv is not None:
-                    dw = wgv[:]
+                    dw = _grad_written(w_param, wgv)
         else:
             gam = grad_amax(dy, g)                          # max|dY|: the gradient operand's scale for both GEMMs
             if ctx.needs_input_grad[0]:
@@ -720,6 +793,10 @@ class LinearFn(torch.autograd.Function):
                 inplace = grads_prezeroed and wgv is not None and (db is None or bgv is not None)
                 dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db, a_amax=gam,
                           out=None if wgv is None else wgv[:], accumulate=inplace)                                   # [N_out, K_in] = g^T x
+                if wgv is not None:                         # written in place: autograd gets None in the direct mode
+                    dw = _grad_written(w_param, wgv)
+                if bgv is not None:
+                    db = _grad_written(b_param, bgv)
             elif want_db:
                 db = colsum(g)
         if has_res and ctx.needs_input_grad[6]:
@@ -852,6 +929,7 @@ class HeadExpandFn(torch.autograd.Function):
         gemm(q2[:, :dh], w2[:dh], trans_b=False, out=u[:, :D], batch=(H, dh, dh * D, D), mode=precision['fwd'])
         ctx.save_for_backward(q2, w2)
         ctx.H = H
+        ctx.w_obj = w                               # the caller's tensor object (a row block of a packed in-projection): its gradient slot
         return u
 
     @staticmethod
@@ -868,8 +946,11 @@ class HeadExpandFn(torch.autograd.Function):
             dq = torch.empty_like(q2)
             gemm(du[:, :D], w2[:dh], trans_b=True, out=dq[:, :dh], batch=(H, D, dh * D, dh), mode=precision['bwd'], a_amax=gam)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w2)
+            wgv = _claim_grad_view(ctx.w_obj) if w2.is_contiguous() else None
+            dw = wgv[:] if wgv is not None else torch.empty_like(w2)
             gemm(q2[:, :dh], du[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'], b_amax=gam)
+            if wgv is not None:
+                dw = _grad_written(ctx.w_obj, wgv)
         return dq, dw, None
 
 
@@ -887,6 +968,7 @@ class HeadContractFn(torch.autograd.Function):
         gemm(c2[:, :D], w2[:dh], trans_b=True, out=o[:, :dh], batch=(H, D, dh * D, dh), mode=precision['fwd'])
         ctx_.save_for_backward(c2, w2)
         ctx_.H = H
+        ctx_.w_obj = w
         return o
 
     @staticmethod
@@ -903,8 +985,11 @@ class HeadContractFn(torch.autograd.Function):
             dc = torch.empty_like(c2)
             gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'], a_amax=gam)
         if ctx_.needs_input_grad[1]:
-            dw = torch.empty_like(w2)
+            wgv = _claim_grad_view(ctx_.w_obj) if w2.is_contiguous() else None
+            dw = wgv[:] if wgv is not None else torch.empty_like(w2)
             gemm(do[:, :dh], c2[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(H, dh, D, dh * D), mode=precision['bwd'], a_amax=gam)
+            if wgv is not None:
+                dw = _grad_written(ctx_.w_obj, wgv)
         return dc, dw, None
 
 
@@ -1027,7 +1112,7 @@ class AddLayerNormFn(torch.autograd.Function):
             dgamma, dbeta, acc_params = ggv[:], bgv[:], 1
         else:
             if ggv is not None:
-                grad_claims.discard(id(ctx.params[0]))
+                _unclaim(ctx.params[0])
             dgb = torch.empty((2, D), device=g.device, dtype=torch.float32)      # side by side: zeroed by one launch
             dgamma, dbeta = dgb[0], dgb[1]
         # every dx_i is somebody's dY: its max|.| is measured while it is written (the producing layer's backward GEMMs scale by it)
@@ -1046,6 +1131,8 @@ class AddLayerNormFn(torch.autograd.Function):
         for o_, a_ in zip(outs, ams):
             if o_ is not None and a_ is not None:
                 tag_amax(o_, a_)
+        if acc_params:
+            dgamma, dbeta = _grad_written(ctx.params[0], ggv), _grad_written(ctx.params[1], bgv)
         return (dgamma, dbeta, None, None, None, None, None, *outs)
 
 

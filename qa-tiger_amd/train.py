@@ -143,6 +143,7 @@ class GradSync:
         self.trace = None                         # set to a list to record ('grad', param index) / ('fire', bucket) / ('finish',) in order
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
+            p._qt_idx = i
         self.begin()
 
     def _make_hook(self, i: int):
@@ -152,15 +153,26 @@ class GradSync:
                 if p.grad.data_ptr() != gv.data_ptr():   # already in place when the producing GEMM wrote into gv
                     gv.copy_(p.grad)
                 p.grad = gv                        # later accumulations (shared weights) add in place
-            if not self._seen[i]:
-                self._seen[i] = True
-                if self.trace is not None:
-                    self.trace.append(('grad', i))
-                b = self.bucket_of[i]
-                self._pending[b] -= 1
-                if self._pending[b] == 0 and not self.defer:
-                    self._fire(b)
+            ent = ops._claimed_rows.get(id(p))
+            if ent is not None and 0 < ent[1] < (p.shape[0] if p.dim() > 0 else 1):
+                return                             # part of this gradient is written in place by producers autograd does not see: finish() fires its bucket
+            self._mark(i)
         return hook
+
+    def _mark(self, i: int):
+        if not self._seen[i]:
+            self._seen[i] = True
+            if self.trace is not None:
+                self.trace.append(('grad', i))
+            b = self.bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self.defer:
+                self._fire(b)
+
+    def _claimed_ready(self, p: Tensor):
+        """ops.grad_ready_cb: every row of p's gradient has been accumulated in place by its producers (no autograd hand-over)."""
+        if getattr(p, '_qt_flat', None) is self.flat or p._qt_gv is self.flat.grad_views[p._qt_idx]:
+            self._mark(p._qt_idx)
 
     def _fire(self, b: int):
         self._fired[b] = True
@@ -174,12 +186,20 @@ class GradSync:
         """Call before backward: forget last step's gradients (grad=None => autograd
         hands over fresh tensors, no memset of the flat buffer needed)."""
         self.flat.check()
-        for p in self.flat.params:
-            p.grad = None
         ops.grad_claims.clear()
+        ops._claimed_rows.clear()
         if self.flat.grad.is_cuda:                # one launch; claimed dW / db producers accumulate into it (ops.grads_prezeroed)
             ops._lib.check(ops._lib.load().qt_zero_f32(ops._stream(), ops._ptr(self.flat.grad), self.flat.grad.numel()), 'qt_zero_f32')
             ops.grads_prezeroed = True                   # first producer of a parameter's gradient this step may write in place
+            # direct mode: .grad IS the (zeroed) slice for the whole step; producers that claim it accumulate there and hand autograd
+            # None, anything autograd still delivers is added in place by AccumulateGrad (no clone, no copy back)
+            for p, gv in zip(self.flat.params, self.flat.grad_views):
+                p.grad = gv
+            ops.direct_grads = True
+            ops.grad_ready_cb = self._claimed_ready
+        else:
+            for p in self.flat.params:
+                p.grad = None
         self._pending = [bk[2] for bk in self.buckets]
         self._seen = [False] * len(self.flat.params)
         self._fired = [False] * len(self.buckets)
@@ -195,6 +215,8 @@ class GradSync:
                 if not seen:
                     self.flat.grad_views[i].zero_()
         ops.grads_prezeroed = False
+        ops.direct_grads = False
+        ops.grad_ready_cb = None
         for b, fired in enumerate(self._fired):
             if not fired:
                 self._fire(b)
