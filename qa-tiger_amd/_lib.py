@@ -162,6 +162,8 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise QTError(f'{LIB_PATH} is missing and could not be built ({e}); '
                           'run `python -c "import __graft_entry__ as g; g.build()"`') from e
+        if str(e).startswith('hipcc failed') or str(e).startswith('hipcc link failed'):
+            raise                                      # the sources changed and do not compile: never run the old library in their place
         # no compiler here: a stale library is caught by the version check below
     lib = C.CDLL(LIB_PATH)
     lib.qt_version.restype = C.c_int

@@ -348,14 +348,19 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
     const bool active = prob < (long)p.n_kv * p.H;
     const int kvn = active ? (int)(prob / p.H) : 0, hd = active ? (int)(prob - (long)kvn * p.H) : 0;
     const int Lq = p.Lq, Lk = p.Lk;
-    const int regA = (2 * KR > 2 * QR ? 2 * KR : 2 * QR) * LDK;        // K|V during phase A, Q|dO during phase B
-    float* base_l = lds + pl * (regA + 2 * KR * LDQ);
+    // LDS holds exactly Lk key rows / Lq query rows, not the 16-row tile multiples: the MFMA tiles' padding rows are read from
+    // the last real row instead (their products are multiplied by probabilities / dS that are exactly 0, or land in output rows
+    // that are never stored).  60x60 attention with d_h = 96: 78.8 KB per workgroup instead of 86 KB -> TWO workgroups per CU;
+    // the 14x14 patch attention: 52.5 KB instead of 60 KB -> three.
+    const int mxr = Lk > Lq ? Lk : Lq;
+    const int regA = 2 * mxr * LDK;                                     // K|V during phase A, Q|dO during phase B
+    float* base_l = lds + pl * (regA + 2 * Lk * LDQ);
     float* Ks = base_l;
-    float* Vs = Ks + KR * LDK;
+    float* Vs = Ks + Lk * LDK;
     float* Qs = base_l;                                                 // overlay (after the phase-A barrier)
-    float* Gs = Qs + QR * LDK;
+    float* Gs = Qs + Lq * LDK;
     float* PT = base_l + regA;                                          // [key][query] dropped P
-    float* ST = PT + KR * LDQ;                                          // [key][query] dS
+    float* ST = PT + Lk * LDQ;                                          // [key][query] dS
     int first = (kvn - p.kv_shift) % p.n_kv;
     if (first < 0) first += p.n_kv;
     const int reps = p.n_items / p.n_kv;                                // uniform trip count (host guarantees divisibility)
@@ -363,10 +368,10 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
     for (int rep = 0; rep < reps; ++rep) {
         const int n = first + rep * p.n_kv;
         __syncthreads();                                                // previous phase B done with Q|dO and PT|ST
-        for (int idx = wip * 64 + lane; idx < KR * V4; idx += wpp * 64) {
+        for (int idx = wip * 64 + lane; idx < Lk * V4; idx += wpp * 64) {
             const int j = idx / V4, c4 = idx - j * V4;
             float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-            if (active && j < Lk) {
+            if (active) {
                 const long row = (long)kvn * p.kv_is + j;
                 kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
                 vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
@@ -396,10 +401,11 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
             for (int kt = 0; kt < NKT; ++kt) {
                 floatx4v a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
                 if (kt * 16 < Lk) {
+                    const int rk = min(kt * 16 + c, Lk - 1);                // (a padding key's score is set to -inf below)
 #pragma unroll
                     for (int ch = 0; ch < DC; ++ch) {
-                        const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + c) * LDK + ch * 16 + g * 4);
-                        const float4 vf = *reinterpret_cast<const float4*>(Vs + (kt * 16 + c) * LDK + ch * 16 + g * 4);
+                        const float4 kf = *reinterpret_cast<const float4*>(Ks + rk * LDK + ch * 16 + g * 4);
+                        const float4 vf = *reinterpret_cast<const float4*>(Vs + rk * LDK + ch * 16 + g * 4);
                         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[ch].x, a1, 0, 0, 0);
                         a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, gf[ch].x, a2, 0, 0, 0);
                         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[ch].y, a1, 0, 0, 0);
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                     delta += dpr * pr;
                     st[kt][j] = pr;
                     dp[kt][j] = dpr;
-                    PT[key * LDQ + q] = pr * mult;                      // dropped P (forward value), for dV
+                    if (key < Lk) PT[key * LDQ + q] = pr * mult;        // dropped P (forward value), for dV
                 }
             delta += __shfl_xor(delta, 16, 64);
             delta += __shfl_xor(delta, 32, 64);
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                 for (int j = 0; j < 4; ++j) {
                     const float ds = st[kt][j] * (dp[kt][j] - delta);
                     st[kt][j] = ds;
-                    ST[(kt * 16 + g * 4 + j) * LDQ + q] = ds;
+                    if (kt * 16 + g * 4 + j < Lk) ST[(kt * 16 + g * 4 + j) * LDQ + q] = ds;
                 }
             floatx4v oacc[DC];
 #pragma unroll
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                 if (kt * 16 >= Lk) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float* krow = Ks + (kt * 16 + g * 4 + j) * LDK + c;
+                    const float* krow = Ks + min(kt * 16 + g * 4 + j, Lk - 1) * LDK + c;      // dS of a padding key is exactly 0
 #pragma unroll
                     for (int dt = 0; dt < DC; ++dt)
                         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][j], krow[dt * 16], oacc[dt], 0, 0, 0);
@@ -479,10 +485,10 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
             }
         }
         __syncthreads();                                                // K|V dead; PT|ST complete
-        for (int idx = wip * 64 + lane; idx < QR * V4; idx += wpp * 64) {
+        for (int idx = wip * 64 + lane; idx < Lq * V4; idx += wpp * 64) {
             const int qi = idx / V4, c4 = idx - qi * V4;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
-            if (active && qi < Lq) {
+            if (active) {
                 t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)qi * p.q_rs) * p.ldq + hd * DH + c4 * 4);
                 u = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)qi * p.do_rs) * p.lddo + hd * DH + c4 * 4);
             }
@@ -496,13 +502,15 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
 #pragma unroll
             for (int dt = 0; dt < DC; ++dt) { av[dt] = floatx4v{0.f, 0.f, 0.f, 0.f}; ak[dt] = av[dt]; }
             for (int qc = 0; qc < nqt; ++qc) {
-                const float4 pf = *reinterpret_cast<const float4*>(PT + (kt * 16 + c) * LDQ + qc * 16 + g * 4);
-                const float4 sf = *reinterpret_cast<const float4*>(ST + (kt * 16 + c) * LDQ + qc * 16 + g * 4);
+                const int rk = min(kt * 16 + c, Lk - 1);                    // a padding key's dK / dV rows are never stored
+                const float4 pf = *reinterpret_cast<const float4*>(PT + rk * LDQ + qc * 16 + g * 4);
+                const float4 sf = *reinterpret_cast<const float4*>(ST + rk * LDQ + qc * 16 + g * 4);
                 const float pa[4] = {pf.x, pf.y, pf.z, pf.w}, sa[4] = {sf.x, sf.y, sf.z, sf.w};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float* grow = Gs + (qc * 16 + g * 4 + s) * LDK + c;
-                    const float* qrow = Qs + (qc * 16 + g * 4 + s) * LDK + c;
+                    const int rq = min(qc * 16 + g * 4 + s, Lq - 1);        // P and dS columns of padding queries are exactly 0
+                    const float* grow = Gs + rq * LDK + c;
+                    const float* qrow = Qs + rq * LDK + c;
 #pragma unroll
                     for (int dt = 0; dt < DC; ++dt) {
                         av[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], grow[dt * 16], av[dt], 0, 0, 0);
@@ -910,8 +918,8 @@ static size_t attn_bwd_mfma_lds(int Lq, int Lk, int dh) {
     const int nqt = (Lq + 15) / 16;
     const int wpp = (nqt > 1 || NKT > 1) ? 4 : 1;
     const int ppb = 4 / wpp;
-    const int LDK = DC * 16 + 4, KR = NKT * 16, QR = nqt * 16, LDQ = QR + 4;
-    const size_t per = (size_t)(2 * (KR > QR ? KR : QR)) * LDK + (size_t)2 * KR * LDQ;
+    const int LDK = DC * 16 + 4, QR = nqt * 16, LDQ = QR + 4;
+    const size_t per = (size_t)(2 * (Lk > Lq ? Lk : Lq)) * LDK + (size_t)2 * Lk * LDQ;
     return sizeof(float) * per * ppb;
 }
 // ONE predicate decides the kernel family from what forward and backward both know (geometry and the q/k/v
@@ -952,8 +960,8 @@ static int launch_bwd_mfma(const AttnArgs& a, hipStream_t st) {
     const int nqt = (a.Lq + 15) / 16;
     const int wpp = (nqt > 1 || NKT > 1) ? 4 : 1;
     const int ppb = 4 / wpp;
-    const int LDK = DC * 16 + 4, KR = NKT * 16, QR = nqt * 16, LDQ = QR + 4;
-    const size_t per = (size_t)(2 * (KR > QR ? KR : QR)) * LDK + (size_t)2 * KR * LDQ;
+    const int LDK = DC * 16 + 4, QR = nqt * 16, LDQ = QR + 4;
+    const size_t per = (size_t)(2 * (a.Lk > a.Lq ? a.Lk : a.Lq)) * LDK + (size_t)2 * a.Lk * LDQ;
     const size_t lds = sizeof(float) * per * ppb;
     if (lds > 160 * 1024) return 1;
     const long probs = (long)a.n_kv * a.H;
