@@ -144,7 +144,8 @@ int qt_moe_coef_fwd(void* stream, const long long* topk_inds, const float* topk_
  * [S*B*T, K*Dh]; modules.py:590-599 + 517-533 with the second layer pulled out of the sum). */
 int qt_moe_treduce_fwd(void* stream, const float* H, const float* coef, int S, int B, int T, int K, int Dh, float* R);
 int qt_moe_treduce_bwd(void* stream, const float* H, const float* coef, const float* dR,
-                       int S, int B, int T, int K, int Dh, float* dH, float* dcoef);
+                       int S, int B, int T, int K, int Dh, float* dH, float* dcoef,
+                       float* dh_amax /* nullable: zeroed max|dH| record (the stacked expert layer's dY scale) */);
 /* dcsum (nullable) is the gradient of csum; it is folded into dcoef on the fly. */
 int qt_moe_router_bwd(void* stream, const float* dcoef, const long long* topk_inds, const float* topk_probs,
                       const float* gauss, const float* probs, const float* gauss_raw, const float* dcsum,

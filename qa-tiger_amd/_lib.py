@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
 SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_plane.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
-ABI_VERSION = 203          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
+ABI_VERSION = 204          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
 FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
@@ -136,7 +136,7 @@ SIGNATURES = {
     'qt_moe_router_fwd': [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p],
     'qt_moe_coef_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'qt_moe_treduce_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
-    'qt_moe_treduce_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    'qt_moe_treduce_bwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     'qt_moe_router_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p],
     'qt_colsum': [_p, _p, _l, _i, _i, _p, _i],
     'qt_add_rows': [_p, _p, _l, _i, _f, _p, _l, _i, _f, _p, _l, _l, _i],

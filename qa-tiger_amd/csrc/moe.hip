@@ -143,10 +143,11 @@ __global__ __launch_bounds__(256) void qt_moe_treduce_fwd_kernel(
 // dcoef[b,t,e] = Σ_s <dR[s*B+b,e,:], H[(s*B+b)*T+t, e, :]>
 __global__ __launch_bounds__(256) void qt_moe_treduce_bwd_kernel(
     const float* __restrict__ H, const float* __restrict__ coef, const float* __restrict__ dR,
-    int S, int B, int T, int K, int Dh, float* __restrict__ dH, float* __restrict__ dcoef) {
+    int S, int B, int T, int K, int Dh, float* __restrict__ dH, float* __restrict__ dcoef, float* __restrict__ dh_amax) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dv = Dh >> 2;
+    float hmax = 0.f;                                        // max |dH| written by this thread (dh_amax: the expert layer's dY scale)
     // work item = (t, e): one wave each, lanes over Dh
     const int t0 = blockIdx.y * MOE_TRB_TPB, tn = min(T - t0, MOE_TRB_TPB);
     for (int item = wave; item < tn * K; item += 4) {
@@ -165,11 +166,17 @@ __global__ __launch_bounds__(256) void qt_moe_treduce_bwd_kernel(
                 float4 o;
                 o.x = h.x > 0.f ? w * g.x : 0.f; o.y = h.y > 0.f ? w * g.y : 0.f;
                 o.z = h.z > 0.f ? w * g.z : 0.f; o.w = h.w > 0.f ? w * g.w : 0.f;
+                hmax = fmaxf(fmaxf(hmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 *reinterpret_cast<float4*>(drow + c4 * 4) = o;
             }
         }
         dot = qt_wave_sum(dot);
         if (lane == 0) dcoef[((long)b * T + t) * K + e] = dot;
+    }
+    if (dh_amax) {
+        hmax = qt_wave_max(hmax);
+        if (lane == 0 && (hmax > 0.f || hmax != hmax))
+            atomicMax(reinterpret_cast<unsigned*>(dh_amax) + ((blockIdx.x + blockIdx.y + wave) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, hmax));
     }
 }
 
@@ -287,12 +294,12 @@ extern "C" int qt_moe_treduce_fwd(void* stream, const float* H, const float* coe
 }
 
 extern "C" int qt_moe_treduce_bwd(void* stream, const float* H, const float* coef, const float* dR,
-                                  int S, int B, int T, int K, int Dh, float* dH, float* dcoef) {
+                                  int S, int B, int T, int K, int Dh, float* dH, float* dcoef, float* dh_amax) {
     QT_CHECK_ARG(H && coef && dR && dH && dcoef, "qt_moe_treduce_bwd: null pointer");
     QT_CHECK_ARG(S > 0 && B > 0 && T > 0 && K > 0 && Dh > 0 && Dh % 4 == 0, "qt_moe_treduce_bwd: Dh=%d must be a multiple of 4", Dh);
     QT_CHECK_ARG(qt_aligned16(H) && qt_aligned16(dR) && qt_aligned16(dH), "qt_moe_treduce_bwd: alignment");
     hipLaunchKernelGGL(qt_moe_treduce_bwd_kernel, dim3(B, (T + MOE_TRB_TPB - 1) / MOE_TRB_TPB), dim3(256), 0, (hipStream_t)stream,
-                       H, coef, dR, S, B, T, K, Dh, dH, dcoef);
+                       H, coef, dR, S, B, T, K, Dh, dH, dcoef, dh_amax);
     QT_CHECK_LAUNCH("qt_moe_treduce_bwd");
     return QT_OK;
 }

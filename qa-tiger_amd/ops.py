@@ -1190,6 +1190,59 @@ class MoECoefFn(torch.autograd.Function):
         return dlogits, draw, None, None, None, None
 
 
+class StackParamsFn(torch.autograd.Function):
+    """K same-shape parameters -> one tensor: 'rows' = cat(dim=0) ([n, m] -> [K n, m]; [n] -> [K n]), 'cols' = cat(dim=1)
+    ([d, n] -> [d, K n]), 'stack1' = stack(dim=1) ([d] -> [d, K]).  The experts of TempMoE are separate modules in the reference
+    (modules.py:386-393, and so in the state_dict); the kernels want them stacked.  torch's own cat costs one kernel forward but
+    K AccumulateGrad additions backward; under train.GradSync the K gradient slots lie at a constant pitch in the flat gradient
+    buffer, so the backward is ONE strided accumulation into all of them (and autograd gets None)."""
+
+    @staticmethod
+    def forward(ctx, mode: str, *params: Tensor):
+        ctx.mode, ctx.plist = mode, params
+        if mode == 'rows':
+            return torch.cat(params, dim=0)
+        if mode == 'cols':
+            return torch.cat(params, dim=1)
+        return torch.stack(params, dim=1)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        mode, params = ctx.mode, ctx.plist
+        K, shp = len(params), params[0].shape
+        if mode == 'rows':
+            gk = g.reshape(K, *shp)
+        elif mode == 'cols':
+            gk = g.reshape(shp[0], K, shp[1]).permute(1, 0, 2)
+        else:
+            gk = g.t()
+        if direct_grads:
+            flat = getattr(params[0], '_qt_flat', None)
+            offs = [getattr(p, '_qt_flat_off', None) for p in params]
+            ok = flat is not None and all(o is not None for o in offs) and all(getattr(p, '_qt_flat', None) is flat and p.shape == shp for p in params)
+            pitch = offs[1] - offs[0] if ok and K > 1 else 0
+            ok = ok and K > 1 and all(offs[e] - offs[0] == e * pitch for e in range(K))
+            if ok:
+                views = [_claim_grad_view(p) for p in params]
+                if all(v is not None for v in views):
+                    inner = [1] * len(shp)
+                    for d in range(len(shp) - 2, -1, -1):
+                        inner[d] = inner[d + 1] * shp[d + 1]
+                    slots = torch.as_strided(flat.grad, (K, *shp), (pitch, *inner), offs[0])
+                    slots.add_(gk)                                   # the buffer was zeroed at the start of the step (grads_prezeroed)
+                    for p, v in zip(params, views):
+                        _grad_written(p, v)
+                    return (None,) * (K + 1)
+                for p, v in zip(params, views):
+                    if v is not None:
+                        _unclaim(p)
+        return (None, *gk.unbind(0))
+
+
+def stack_params(mode: str, params: Sequence[Tensor]) -> Tensor:
+    return StackParamsFn.apply(mode, *params)
+
+
 class MoEReduceFn(torch.autograd.Function):
     """R[s*B+b, e, :] = Σ_t coef[b,t,e] · H[(s*B+b)*T+t, e, :].  The returned dH
     already carries the ReLU mask of H (H is a ReLU output)."""
@@ -1215,8 +1268,11 @@ class MoEReduceFn(torch.autograd.Function):
         dR = dR.contiguous()
         dH = torch.empty_like(H)
         dcoef = torch.empty_like(coef)
-        rc = _lib.load().qt_moe_treduce_bwd(_stream(), _ptr(H), _ptr(coef), _ptr(dR), S, B, T, K, Dh, _ptr(dH), _ptr(dcoef))
+        ham = new_amax(H.device) if precision['bwd'] == 'f16x3' else None
+        rc = _lib.load().qt_moe_treduce_bwd(_stream(), _ptr(H), _ptr(coef), _ptr(dR), S, B, T, K, Dh, _ptr(dH), _ptr(dcoef), _ptr(ham))
         _lib.check(rc, 'qt_moe_treduce_bwd')
+        if ham is not None:
+            tag_amax(dH, ham)                           # the stacked expert layer's backward GEMMs scale dH by it
         return dH, dcoef, None, None
 
 

@@ -247,10 +247,10 @@ class TempMoE(nn.Module):
         coef, csum, ti, tp, gauss = ops.MoECoefFn.apply(logits, raw, T, K, k, float(self.sigma))
         self.last = dict(temp_w=temp_w.detach(), router_logits=logits.detach(), topk_inds=ti, topk_probs=tp, gauss=gauss)
         # all experts, first layer, as one GEMM over the stacked streams
-        w1 = torch.cat([e[0].weight for e in self.experts], dim=0)        # [K*Dh, D]
-        b1 = torch.cat([e[0].bias for e in self.experts], dim=0)
-        w2 = torch.cat([e[2].weight for e in self.experts], dim=1)        # [D, K*Dh]
-        b2t = torch.stack([e[2].bias for e in self.experts], dim=1)       # [D, K]
+        w1 = ops.stack_params('rows', [e[0].weight for e in self.experts])        # [K*Dh, D]
+        b1 = ops.stack_params('rows', [e[0].bias for e in self.experts])
+        w2 = ops.stack_params('cols', [e[2].weight for e in self.experts])        # [D, K*Dh]
+        b2t = ops.stack_params('stack1', [e[2].bias for e in self.experts])       # [D, K]
         d2 = data.reshape(B * T, D)
         if sub_data is not None:
             S = len(sub_data)
