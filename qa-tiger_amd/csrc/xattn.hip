@@ -259,7 +259,147 @@ __global__ __launch_bounds__(XA_NT, 2) void qt_xattn_fwd_mfma_kernel(XAttnArgs p
     }
 }
 
-// Backward.  Phase 1 (wave per pair of (query, head) vectors, rows staged chunk-wise): recompute
+// MFMA backward for the same shape class (at most 16 (query, head) vectors r, at most 16 key rows p, D = 128 DB).  Per item the
+// backward is five small products with D as the long dimension:
+//     S = U X^T and dA = G X^T (16 x 16 x D, G = dctx),  dU = scale dS X (16 x D x 16),  dX = A_d^T G + scale dS^T U (16 x D x 16, twice)
+// with a = exp(scale S - lse), A_d = a mult (dropout), dS = a (mult (dA + dasum) - delta), delta_r = g_r.ctx_r + dasum_r asum_r.
+// The VALU kernel below spends its time issuing dot products (33 % of the HBM rate).  Here, as in the forward:
+//   * the D columns are split over the 8 waves in 16-column blocks; a lane (r16, kq) loads columns 4 kq .. 4 kq + 3 of row r16 of
+//     U, G, ctx and X for each of its blocks ONCE (16-byte loads) and keeps them in registers for the whole item;
+//   * partial S and dA tiles (and the partial row dots of delta) over the wave's columns meet in LDS (one __syncthreads per item);
+//     every wave then holds a, A_d and scale dS in the MFMA result layout (key on the lane, 4 rows in registers);
+//   * dU and dX blocks are computed TRANSPOSED (the A operand is X^T / G^T / U^T of the block: a 16 x 16 register transpose
+//     through a 1 KiB per-wave LDS tile; the B operand is the small matrix, read from the wave's LDS copy in operand layout), so a
+//     lane ends up with four consecutive columns of one output row -> 16-byte stores.
+// No row is staged in LDS: 25 KiB per workgroup.
+template <int DB>
+__global__ __launch_bounds__(XA_NT, 2) void qt_xattn_bwd_mfma_kernel(XAttnArgs p) {
+    if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
+    constexpr int D = 128 * DB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Sp = lds;                                   // [8][16][16] partial S tiles
+    float* Dp = Sp + 8 * 256;                          // [8][16][16] partial dA tiles
+    float* Dl = Dp + 8 * 256;                          // [8][16] partial g.ctx row dots
+    float* Wv = Dl + 8 * 16;                           // per wave: Ad [16][17], Ds [16][17], T [16][17]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.x, NQ = p.Lq * p.H, Lk = p.Lk;
+    const float* xbase = p.x + (long)n * Lk * D;
+    auto urow_of = [&](int qh) { const int qq = min(qh, NQ - 1); const int i = qq / p.H, h = qq - i * p.H;
+                                 return ((long)n * p.u_is + (long)i * p.u_rs) * p.H + h; };
+    float* Am = Wv + wave * (3 * 16 * 17);
+    float* Dm = Am + 16 * 17;
+    float* Tm = Dm + 16 * 17;
+    const long ur16 = urow_of(r16);
+    const bool uok = r16 < NQ, xok = r16 < Lk;
+    float4 ua[DB], ga[DB], xb[DB];
+    xa_f4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+    float dlt = 0.f;
+    {
+        const float* up = p.u + ur16 * D + 4 * kq;
+        const float* gp = p.dctx + ur16 * D + 4 * kq;
+        const float* cp = p.ctx_in + ur16 * D + 4 * kq;
+        const float* xp = xbase + (long)min(r16, Lk - 1) * D + 4 * kq;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            const int cb = (wave * DB + b) * 16;
+            ua[b] = uok ? *reinterpret_cast<const float4*>(up + cb) : z;
+            ga[b] = uok ? *reinterpret_cast<const float4*>(gp + cb) : z;
+            xb[b] = xok ? *reinterpret_cast<const float4*>(xp + cb) : z;
+            const float4 ca = uok ? *reinterpret_cast<const float4*>(cp + cb) : z;
+            dlt += dot4(ga[b], ca);
+        }
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].x, xb[b].x, sacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[b].x, xb[b].x, dacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].y, xb[b].y, sacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[b].y, xb[b].y, dacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].z, xb[b].z, sacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[b].z, xb[b].z, dacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].w, xb[b].w, sacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[b].w, xb[b].w, dacc, 0, 0, 0);
+        }
+    }
+    dlt += __shfl_xor(dlt, 16, 64);
+    dlt += __shfl_xor(dlt, 32, 64);                    // row r16's dot over this wave's columns, on all four kq lanes
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        Sp[wave * 256 + (4 * kq + reg) * 16 + r16] = sacc[reg];
+        Dp[wave * 256 + (4 * kq + reg) * 16 + r16] = dacc[reg];
+    }
+    if (kq == 0) Dl[wave * 16 + r16] = dlt;
+    __syncthreads();
+    // full tiles in every wave (key = r16 on the lane, rows 4 kq + reg in registers) -> a, A_d, scale dS into the wave's LDS copy
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int qh = 4 * kq + reg;
+        float sv = 0.f, dav = 0.f, dl = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { sv += Sp[w * 256 + qh * 16 + r16]; dav += Dp[w * 256 + qh * 16 + r16]; dl += Dl[w * 16 + qh]; }
+        const long ur = urow_of(qh);
+        const float das = p.dasum ? p.dasum[ur] : 0.f;
+        const float delta = dl + das * p.asum[ur];
+        const bool ok = qh < NQ && r16 < Lk;
+        const float a = ok ? __expf(sv * p.scale - p.lse[ur]) : 0.f;
+        const float mult = (p.drop_p > 0.f && ok) ? qt_drop_mult(p.seed, (unsigned long long)ur * Lk + r16, p.drop_p, p.inv_keep) : 1.0f;
+        const float ds = a * ((dav + das) * mult - delta);
+        Am[qh * 17 + r16] = a * mult;
+        Dm[qh * 17 + r16] = ds * p.scale;
+    }
+    // operand-layout copies: B[k = 4 j + kq][col = r16]
+    float dsb[4], dsk[4], adk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dsb[j] = Dm[r16 * 17 + 4 * j + kq];            // dU: k = key 4 j + kq, col = row r16:   scale dS[r16][key]
+        dsk[j] = Dm[(4 * j + kq) * 17 + r16];          // dX: k = row 4 j + kq, col = key r16:   scale dS[row][r16]
+        adk[j] = Am[(4 * j + kq) * 17 + r16];          //                                         A_d[row][r16]
+    }
+    float xmax = 0.f, umax = 0.f;
+    float* dxrow = p.dx + ((long)n * Lk + min(r16, Lk - 1)) * D + 4 * kq;
+    float* durow = p.du + ur16 * D + 4 * kq;
+    auto transpose = [&](const float4& v, float (&t)[4]) {          // t[j] = V[row 4 j + kq][column r16 of the block]
+        Tm[r16 * 17 + 4 * kq + 0] = v.x; Tm[r16 * 17 + 4 * kq + 1] = v.y; Tm[r16 * 17 + 4 * kq + 2] = v.z; Tm[r16 * 17 + 4 * kq + 3] = v.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = Tm[(4 * j + kq) * 17 + r16];
+    };
+#pragma unroll
+    for (int b = 0; b < DB; ++b) {
+        const int cb = (wave * DB + b) * 16;
+        float xt[4], gt[4], ut[4];
+        transpose(xb[b], xt);
+        transpose(ga[b], gt);
+        transpose(ua[b], ut);
+        xa_f4 au = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            au = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[j], dsb[j], au, 0, 0, 0);     // dU[r16][cb + 4 kq + reg]
+            ax = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[j], adk[j], ax, 0, 0, 0);     // dX[key r16][cb + 4 kq + reg]
+            ax = __builtin_amdgcn_mfma_f32_16x16x4f32(ut[j], dsk[j], ax, 0, 0, 0);
+        }
+        if (uok) {
+            umax = fmaxf(fmaxf(umax, fmaxf(fabsf(au[0]), fabsf(au[1]))), fmaxf(fabsf(au[2]), fabsf(au[3])));
+            *reinterpret_cast<float4*>(durow + cb) = make_float4(au[0], au[1], au[2], au[3]);
+        }
+        if (xok) {
+            xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(ax[0]), fabsf(ax[1]))), fmaxf(fabsf(ax[2]), fabsf(ax[3])));
+            *reinterpret_cast<float4*>(dxrow + cb) = make_float4(ax[0], ax[1], ax[2], ax[3]);
+        }
+    }
+    if (p.dx_amax) {
+        xmax = qt_wave_max(xmax);
+        if (lane == 0 && (xmax > 0.f || xmax != xmax))
+            atomicMax(reinterpret_cast<unsigned*>(p.dx_amax) + ((blockIdx.x + wave) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, xmax));
+    }
+    if (p.du_amax) {
+        umax = qt_wave_max(umax);
+        if (lane == 0 && (umax > 0.f || umax != umax))
+            atomicMax(reinterpret_cast<unsigned*>(p.du_amax) + ((blockIdx.x + wave) & (QT_AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, umax));
+    }
+}
+
+// Backward, any shape.  Phase 1 (wave per pair of (query, head) vectors, rows staged chunk-wise): recompute
 // a_p = exp(s_p - lse), da_p = dctx·x_p + dasum, ds_p = a_p (mult_p da_p - delta) with
 // delta = dctx·ctx + dasum·asum; dU += ds_p x_p in registers; the scalars a_d[q,p], scale·ds[q,p] and the
 // u / dctx rows are parked in LDS.  Phase 2 (wave per key row): dX_p = Σ_q a_d[q,p] dctx_q + scale ds[q,p] u_q
@@ -517,6 +657,16 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     a.u_is = u_is; a.u_rs = u_rs; a.n_items = n_items; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D; a.scale = scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr; a.du = du; a.dx = dx; a.dx_amax = dx_amax; a.du_amax = du_amax;
     const int NQ = Lq * H;
+    hipStream_t st = (hipStream_t)stream;
+    static int force_valu = -1;
+    if (force_valu < 0) { const char* e = getenv("QT_XATTN_BWD_VALU"); force_valu = (e && atoi(e)) ? 1 : 0; }
+    if (!force_valu && NQ <= 16 && Lk <= 16 && (D == 768 || D == 1024)) {       // the PatchSelecter shape class: all five products on the f32 MFMA
+        const size_t mlds = sizeof(float) * ((size_t)2 * 8 * 256 + 8 * 16 + 8 * 3 * 16 * 17);
+        if (D == 768) hipLaunchKernelGGL(qt_xattn_bwd_mfma_kernel<6>, dim3(n_items), dim3(XA_NT), mlds, st, a);
+        else hipLaunchKernelGGL(qt_xattn_bwd_mfma_kernel<8>, dim3(n_items), dim3(XA_NT), mlds, st, a);
+        QT_CHECK_LAUNCH("qt_xattn_bwd(mfma)");
+        return QT_OK;
+    }
     a.gq = NQ < 16 ? ((NQ + 1) / 2) * 2 : 16;
     size_t lds = 0;
     // u and dctx rows both parked in LDS when that leaves room for two workgroups per CU; otherwise (and if every
@@ -528,7 +678,6 @@ extern "C" int qt_xattn_bwd(void* stream, const float* u, long u_is, long u_rs, 
     }
     if (a.bch < 1) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_xattn_bwd: D=%d, Lk=%d, Lq*H=%d needs %zu B of LDS (>160 KiB)", D, Lk, NQ, lds);
     const int nvl = (D / 4 + 63) / 64;
-    hipStream_t st = (hipStream_t)stream;
 #define XA_BWD(NV_) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)qt_xattn_bwd_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          hipLaunchKernelGGL(qt_xattn_bwd_kernel<NV_>, dim3(n_items), dim3(XA_NT), lds, st, a); } while (0)
     if (nvl == 1) XA_BWD(1); else if (nvl == 2) XA_BWD(2); else if (nvl == 3) XA_BWD(3); else XA_BWD(4);

@@ -349,9 +349,10 @@ def test_folded_attention_matches_projected_attention(ops, n_items, Lq, Lk, E, u
     assert float(gb[:2 * E].abs().max()) == 0 and float(gW[:E].abs().max()) == 0   # q block not used here; key bias has zero true gradient
 
 
-def test_folded_attention_mfma_forward_and_valu_backward_share_the_dropout_mask(ops):
-    """PatchSelecter shape: the forward runs on the f32 MFMA kernel, the backward on the VALU kernel; both must draw the same
-    attention-probability dropout mask from (seed, row, key): first-order check <dO, out(x + d) - out(x)> = <dx, d>."""
+def test_folded_attention_mfma_forward_and_backward_share_the_dropout_mask(ops):
+    """PatchSelecter shape: forward and backward run on their f32 MFMA kernels (qt_xattn_fwd_mfma_kernel / qt_xattn_bwd_mfma_kernel);
+    both must draw the same attention-probability dropout mask from (seed, row, key): first-order check
+    <dO, out(x + d) - out(x)> = <dx, d>."""
     n_items, Lq, Lk, E, H, p = 20, 2, 14, 768, 8, 0.1
     torch.manual_seed(1)
     mha = torch.nn.MultiheadAttention(E, H).to(DEV)
