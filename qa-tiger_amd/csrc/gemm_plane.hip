@@ -90,14 +90,20 @@ template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_
 // WMT: 32-row MFMA tiles per wave along M.  4 = the 256-row tile; 3 = a 192-row tile for problems whose 256-row tiling leaves the last
 //      round of the persistent walk mostly empty (M = 30720, N = 768: 360 tiles on 256 CUs = 2 rounds at 70 %; 480 tiles of 192 rows = 94 %).
 //      Row-form fp16 A operands only; the B tile, the LDS map and the stage pitch are unchanged (an A stage just uses 24 of its 32 KiB).
-template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4>
-__global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
+// NWM: wave rows.  2 = 8 waves (2 x 4) of (32 WMT) x 64; 4 = SIXTEEN waves (4 x 4) of 64 x 64 on the same 256 x 256 tile (WMT = 2): four
+//      waves per SIMD instead of two to cover the per-K-step barrier + first-fragment bubble.  Measured and NOT instantiated: at the
+//      128 registers a wave then gets, the epilogue spills (214-327 registers) and the loop reads 1.33x more LDS per MFMA:
+//      215040x2304x768 2.06 -> 2.69 ms, the dX orientation 1.93 -> 5.76 ms (tools/ab_waves16.py at commit time).
+template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4, int NWM = 2>
+__global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
     if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
     constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
-    static_assert(WMT == 4 || (WMT == 3 && !AKS && FMT == 0), "the 192-row tile exists for row-form fp16 A operands only");
+    static_assert((NWM == 2 && (WMT == 4 || (WMT == 3 && !AKS && FMT == 0))) || (NWM == 4 && WMT == 2 && FMT == 0),
+                  "tile shapes: 8 waves x (128|96) x 64, or 16 waves x 64 x 64");
     constexpr int WNT = 2, NWN = 4;                   // wave tile (32 WMT) x 64 = WMT x 2 MFMA tiles of 32 x 32
-    constexpr int BM = 2 * WMT * 32, BN = 256, GM = 4;
+    constexpr int BM = NWM * WMT * 32, BN = 256, GM = 4;
+    constexpr int NBP = 32 / (NWM * NWN);              // 1 KiB DMA pieces of the B tile per wave (A: WMT per wave)
     constexpr int NS = 2 * WMT;                       // compute segments per K step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     };
 
     // ---- per-lane DMA source offsets (bytes from the operand base), 4 pieces of 1 KiB per operand per wave
-    unsigned offA[WMT], offB[4];
+    unsigned offA[WMT], offB[NBP];
     auto set_offsets = [&]() {
 #pragma unroll
         for (int i = 0; i < WMT; ++i) {
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = wave * 4 + i;                         // piece 0..31 of the 32 KiB B tile
+        for (int i = 0; i < NBP; ++i) {
+            const int pc = wave * NBP + i;                       // piece 0..31 of the 32 KiB B tile
             if (!BKS) {
                 const int row = pc * 8 + (lane >> 3);
                 const int sl = (lane & 7) ^ ((row >> 1) & 7);
@@ -169,13 +175,13 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
         const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
-        qt_dma16(lds0 + P_B_BASE + stage * P_OPER + wave * 4096 + i * 1024, sb, offB[i]);
+        qt_dma16(lds0 + P_B_BASE + stage * P_OPER + wave * (NBP * 1024) + i * 1024, sb, offB[i]);
     };
     auto dma_b = [&](int k0, int stage) {
         const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
-        const unsigned lb = lds0 + P_B_BASE + stage * P_OPER + wave * 4096;
+        const unsigned lb = lds0 + P_B_BASE + stage * P_OPER + wave * (NBP * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qt_dma16(lb + i * 1024, sb, offB[i]);
+        for (int i = 0; i < NBP; ++i) qt_dma16(lb + i * 1024, sb, offB[i]);
     };
 
     // ---- per-lane fragment read offsets inside a stage
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (!AKS) fa[c] = (unsigned)((wm * (WMT * 32) + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);   // c = hl*2 + s
-            else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 8) * 64 + ((c ^ q) * 64));   // c = unit & 3
+            else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 2 * WMT) * 64 + ((c ^ q) * 64));   // c = unit & 3
             if (!BKS) fb[c] = (unsigned)((wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
             else      fb[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
         }
@@ -345,7 +351,8 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             // number of stores, which ragged tiles make data-dependent).
             if (t > 0 && t + 1 < nk) {
                 if constexpr (WMT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if constexpr (WMT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
@@ -354,12 +361,12 @@ __global__ __launch_bounds__(512, 2) void qt_gemm_ps_kernel(PlaneArgs p) {
             const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
             auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), then the WMT pieces of A(t+2) — this order is what vmcnt(WMT) counts on
                 constexpr int seg = decltype(SEG)::value;
-                if constexpr (seg < 4) { if (do_b) dma_b1(kb1, stb, seg); }
+                if constexpr (seg < NBP) { if (do_b) dma_b1(kb1, stb, seg); }
                 else {
-                    if (do_a) dma_a1(ka2, sta, seg - 4);
+                    if (do_a) dma_a1(ka2, sta, seg - NBP);
                     if constexpr (seg == NS - 1) {             // 192-row tile: 6 segments carry 4 + 3 pieces, the last one two
 #pragma unroll
-                        for (int e = NS - 4; e < WMT; ++e) if (do_a) dma_a1(ka2, sta, e);
+                        for (int e = NS - NBP; e < WMT; ++e) if (do_a) dma_a1(ka2, sta, e);
                     }
                 }
             };
