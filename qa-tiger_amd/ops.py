@@ -711,12 +711,16 @@ class LinearFn(torch.autograd.Function):
         if y is None:
             ximg = wimg = None
             wam = weight_amax(weight) if weight.shape[1] % 4 == 0 else None
+            xam = act_amax(x, x2)
             y = gemm(x2, weight, trans_b=True, bias=bias, add=residual, relu=relu, drop_p=drop_p, seed=seed, mode=precision['fwd'],
-                     a_amax=act_amax(x, x2), b_amax=wam)
+                     a_amax=xam, b_amax=wam)
             ctx.wam = wam
+            ctx.xam = xam                                # robust-range mode: the dW GEMM scales the saved input by the same record
         # the plane path saves the input's IMAGE (same bytes) for the dW GEMM, not the fp32 rows
         ctx.save_for_backward(x2 if ximg is None else ximg.data, weight, y if relu else None)
         ctx.used_plane = ximg is not None
+        if ximg is not None:
+            ctx.xam = ximg.amax                          # None unless the robust-range mode scaled the input's image
         ctx.wimg = wimg                             # the weight's image (weights do not change between forward and backward)
         ctx.params = (weight, bias)                 # the Parameter objects themselves (saved tensors come back as new objects)
         ctx.cfg = (relu, drop_p, seed, bias is not None, residual is not None, grad_premasked, shape)
@@ -745,7 +749,7 @@ class LinearFn(torch.autograd.Function):
             if bgv is not None:
                 db = _grad_written(b_param, bgv)
             wimg = ctx.wimg
-            ximg = SplitImage(x2, x2.shape[0], x2.shape[1], None)
+            ximg = SplitImage(x2, x2.shape[0], x2.shape[1], ctx.xam)
             if ctx.needs_input_grad[0]:
                 # max|dX| is measured by the epilogue that stores it and rides on the tensor autograd hands to dX's consumer
                 cam = new_amax(g.device)
@@ -792,6 +796,7 @@ class LinearFn(torch.autograd.Function):
                 wgv = _claim_grad_view(w_param)
                 inplace = grads_prezeroed and wgv is not None and (db is None or bgv is not None)
                 dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db, a_amax=gam,
+                          b_amax=ctx.xam if precision['bwd'] == 'f16x3' else None,
                           out=None if wgv is None else wgv[:], accumulate=inplace)                                   # [N_out, K_in] = g^T x
                 if wgv is not None:                         # written in place: autograd gets None in the direct mode
                     dw = _grad_written(w_param, wgv)
