@@ -358,7 +358,7 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
         mask_src = as2d(mask_src)
     rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(a_kslow), int(b_kslow), 'ps'), lambda: _lib.load().qt_gemm_ps(
         _stream(), int(a_kslow), int(b_kslow), M, N, K, float(alpha),
-        _ptr(a.data), 4 * a.cols, _ptr(a.amax), _ptr(b.data), 4 * b.cols, _ptr(b.amax),
+        _ptr(a.data), 4 * a.data.stride(0), _ptr(a.amax), _ptr(b.data), 4 * b.data.stride(0), _ptr(b.amax),       # (a column block of an image is an image)
         _ptr(out), _ld(out), _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
         float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), _ptr(c_amax)))
@@ -931,7 +931,21 @@ class HeadExpandFn(torch.autograd.Function):
         M, E = q2.shape
         D, dh = w2.shape[1], E // H
         u = torch.empty((M, H * D), device=q2.device, dtype=torch.float32)
-        gemm(q2[:, :dh], w2[:dh], trans_b=False, out=u[:, :D], batch=(H, dh, dh * D, D), mode=precision['fwd'])
+        done = False
+        if _plane_ok(M, D, E) and dh % 32 == 0 and D % 4 == 0:
+            # per head on the pre-split kernel: A = the head's column block of q's image, B = the head's row block of W's image read
+            # K-slow; the launch is bound by writing its [M, D] slab of u (94 MB at the primary config), which the float4 epilogue does
+            wimg = weight_image(w)
+            if wimg is not None:
+                qimg = input_image(q, q2)
+                for h in range(H):
+                    a = SplitImage(qimg.data[:, h * dh:(h + 1) * dh], M, dh, qimg.amax)
+                    b = SplitImage(wimg.data[h * dh:(h + 1) * dh], dh, D, wimg.amax)
+                    if gemm_ps(a, b, b_kslow=True, out=u[:, h * D:(h + 1) * D], split_k=1) is None:
+                        raise _lib.QTError('qt_gemm_ps refused a head slab of the fold GEMM')
+                done = True
+        if not done:
+            gemm(q2[:, :dh], w2[:dh], trans_b=False, out=u[:, :D], batch=(H, dh, dh * D, D), mode=precision['fwd'])
         ctx.save_for_backward(q2, w2)
         ctx.H = H
         ctx.w_obj = w                               # the caller's tensor object (a row block of a packed in-projection): its gradient slot
@@ -988,7 +1002,20 @@ class HeadContractFn(torch.autograd.Function):
         dc = dw = None
         if ctx_.needs_input_grad[0]:
             dc = torch.empty_like(c2)
-            gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'], a_amax=gam)
+            done = False
+            M = do.shape[0]
+            if _plane_ok(M, D, H * dh) and dh % 32 == 0 and D % 4 == 0 and gam is not None:
+                wimg = weight_image(ctx_.w_obj)
+                if wimg is not None:                    # same slab structure as HeadExpandFn.forward: dC_h = dO_h W_v,h
+                    gimg = split_image(do, amax=gam)
+                    for h in range(H):
+                        a = SplitImage(gimg.data[:, h * dh:(h + 1) * dh], M, dh, gam)
+                        b = SplitImage(wimg.data[h * dh:(h + 1) * dh], dh, D, wimg.amax)
+                        if gemm_ps(a, b, b_kslow=True, out=dc[:, h * D:(h + 1) * D], split_k=1) is None:
+                            raise _lib.QTError('qt_gemm_ps refused a head slab of the fold GEMM')
+                    done = True
+            if not done:
+                gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'], a_amax=gam)
         if ctx_.needs_input_grad[1]:
             wgv = _claim_grad_view(ctx_.w_obj) if w2.is_contiguous() else None
             dw = wgv[:] if wgv is not None else torch.empty_like(w2)
