@@ -200,6 +200,11 @@ class GradSync:
         else:
             for p in self.flat.params:
                 p.grad = None
+        self.reset_host_state()
+
+    def reset_host_state(self):
+        """The host-side bookkeeping of begin().  A captured train step replays begin()'s DEVICE work only (GraphedTrainStep calls
+        this before every replay: without it the second replay would find every bucket marked as already reduced)."""
         self._pending = [bk[2] for bk in self.buckets]
         self._seen = [False] * len(self.flat.params)
         self._fired = [False] * len(self.buckets)
@@ -380,7 +385,7 @@ class GraphedTrainStep:
         dev = engine.flat.flat.device
         if dev.type != 'cuda':
             raise ops._lib.QTError('GraphedTrainStep needs an MI355X (cuda) device')
-        self.distributed = engine.sync.world > 1
+        self.distributed = engine.sync.world > 1 or engine.sync.force_collective
         self.lib = ops._lib.load()
         self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
         ops._lib.check(self.lib.qt_set_dropout_salt(ops._ptr(self.salt)), 'qt_set_dropout_salt')     # library-global: one engine per process
@@ -402,6 +407,10 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.static_loss = self._captured_part()
         engine.optim.step_count = steps_before + warmup      # the capture pass records work, it does not run it
+        if self.distributed:                            # the captured begin() left its host flags set; finish() (eager part) clears them per step
+            ops.grads_prezeroed = False
+            ops.direct_grads = False
+            ops.grad_ready_cb = None
 
     def _captured_part(self) -> Tensor:
         eng = self.eng
@@ -425,8 +434,10 @@ class GraphedTrainStep:
         for k, v in self.static_in.items():
             if isinstance(v, Tensor) and batch[k] is not v:
                 v.copy_(batch[k], non_blocking=True)
+        self.eng.sync.reset_host_state()                # (begin() ran at capture time only)
         self.graph.replay()
         if self.distributed:
+            ops.grads_prezeroed = True                  # the replayed begin() zeroed the gradient buffer: finish() must not zero "unseen" slices
             self._eager_part()
         else:
             self.eng.optim.step_count += 1

@@ -105,6 +105,25 @@ def main(rank: int, world: int, port: int) -> int:
         rep['vs_local_weight_diff_max'], rep['vs_local_weight_diff_median'] = float(d.max()), float(d.median())
         rep['vs_local_frac_above_1e-6'] = float((d > 1e-6).float().mean())
         ok = ok and float(d.max()) <= 3.5e-4 and float(d.median()) < 1e-7 and rep['vs_local_frac_above_1e-6'] < 0.02
+    # ---- the captured step with a process group (bench.py --graph auto at per-GPU batches <= 64: the 8-GPU strong-scaling point):
+    # forward + backward replay from the graph, the bucket all-reduces and the optimizer run eagerly after it — on EVERY call
+    eager = engine(64 << 10, with_group=True)
+    cap = engine(64 << 10, with_group=True)
+    gstep = qt.GraphedTrainStep(cap, shard, warmup=2)
+    n_calls = 3
+    for _ in range(2 + n_calls):
+        eager.step(shard)
+    cap.sync.trace = []
+    for _ in range(n_calls):
+        gstep(shard)
+    torch.cuda.synchronize()
+    fires = sum(1 for e in cap.sync.trace if e[0] == 'fire')
+    cap.sync.trace = None
+    rep['graph_fires_per_call'] = fires / n_calls
+    ok = ok and fires == n_calls * len(cap.sync.buckets)
+    dg = (cap.flat.flat - eager.flat.flat).abs()
+    rep['graph_vs_eager_weight_diff_max'], rep['graph_vs_eager_frac_above_1e-6'] = float(dg.max()), float((dg > 1e-6).float().mean())
+    ok = ok and float(dg.max()) <= 6e-4 and float(dg.median()) < 1e-7 and rep['graph_vs_eager_frac_above_1e-6'] < 0.03
     okt = torch.tensor([1.0 if ok else 0.0], device=dev)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)
     ok = bool(okt.item() > 0)
