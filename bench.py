@@ -62,7 +62,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=100.0, help='seconds of CPU work the bounded CPU-baseline sample may take (it picks the largest batch <= 256 that fits)')
     ap.add_argument('--cpu-sample', type=int, default=0, help='force the batch of the CPU-baseline sample (0 = pick by --cpu-budget)')
-    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto', help='replay the train step from one HIP graph (qt.GraphedTrainStep). auto = when the per-GPU batch is <= 64, where eager steps are host-bound (the 8-GPU strong-scaling shard is B=32)')
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto', help='replay the train step from one HIP graph (qt.GraphedTrainStep). auto = single-rank runs whose batch is <= 64; multi-rank runs stay eager (overlapped bucket all-reduces) unless --graph on')
     ap.add_argument('--no-strict-fp32', action='store_true', help='skip the exact-fp32 MFMA (QT_GEMM=fp32) comparison line')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL over xGMI; gloo only for rehearsals)')
     ap.add_argument('--skip-fwd-only', action='store_true', help='skip the forward-only passes (used by tools/pmc_step_traffic.sh so that every profiled launch belongs to a train step)')
@@ -235,7 +235,11 @@ def main():
             return float(tmax)
         return dt
 
-    use_graph = args.graph == 'on' or (args.graph == 'auto' and per_gpu <= 64)
+    # auto: only without a process group.  The captured step was worth 12.3 -> 10.1 ms at B=32 while eager steps were host-bound; since the
+    # launch-count work of round 2 eager and captured steps take the same 9.7 ms there, and the replay + eager all-reduce combination
+    # has only been exercised through RCCL on ONE rank (tests/rccl_driver.py) — a 2-rank gloo rehearsal on one shared GPU took 10 s per
+    # step — so a multi-rank run stays on the eager path (bucket all-reduces overlapped with backward) unless --graph on is given.
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and per_gpu <= 64 and world == 1)
     step_fn = (lambda: eng.step(batch))
     if use_graph:
         gstep = qt.GraphedTrainStep(eng, batch, warmup=max(2, args.warmup))
