@@ -919,6 +919,7 @@ def attention(qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: flo
 # few-query attention with the K/V projections folded away (csrc/xattn.hip)
 # --------------------------------------------------------------------------- #
 fold_kv = True      # PatchSelecter.crs_attn (Lq=2) and TempMoE.qst_attn (Lq=1) skip the K/V projection GEMMs
+fold_slab_min_rows = 8192   # query rows from which the H head slabs of the fold GEMMs go to the pre-split kernel one launch each (below: one head-batched launch)
 
 
 class HeadExpandFn(torch.autograd.Function):
@@ -932,7 +933,7 @@ class HeadExpandFn(torch.autograd.Function):
         D, dh = w2.shape[1], E // H
         u = torch.empty((M, H * D), device=q2.device, dtype=torch.float32)
         done = False
-        if _plane_ok(M, D, E) and dh % 32 == 0 and D % 4 == 0:
+        if M >= fold_slab_min_rows and _plane_ok(M, D, E) and dh % 32 == 0 and D % 4 == 0:
             # per head on the pre-split kernel: A = the head's column block of q's image, B = the head's row block of W's image read
             # K-slow; the launch is bound by writing its [M, D] slab of u (94 MB at the primary config), which the float4 epilogue does
             wimg = weight_image(w)
@@ -1004,7 +1005,7 @@ class HeadContractFn(torch.autograd.Function):
             dc = torch.empty_like(c2)
             done = False
             M = do.shape[0]
-            if _plane_ok(M, D, H * dh) and dh % 32 == 0 and D % 4 == 0 and gam is not None:
+            if M >= fold_slab_min_rows and _plane_ok(M, D, H * dh) and dh % 32 == 0 and D % 4 == 0 and gam is not None:
                 wimg = weight_image(ctx_.w_obj)
                 if wimg is not None:                    # same slab structure as HeadExpandFn.forward: dC_h = dO_h W_v,h
                     gimg = split_image(do, amax=gam)

@@ -310,7 +310,7 @@ def test_attention_streaming_dropout_consistency(ops):
                                                       # the MFMA forward's shape class (<= 16 (query, head) vectors, <= 16 keys, D 768 / 1024):
                                                       (12, 2, 16, 1024, 1, 12), (9, 2, 5, 768, 1, 9), (6, 1, 9, 768, 1, 0),
                                                       # >= 2048 query rows: the head-slab GEMMs (u = q_h W_k,h and dC_h = dO_h W_v,h) run on the pre-split kernel
-                                                      (1100, 2, 4, 768, 1, 1100)])
+                                                      (4200, 2, 2, 768, 1, 4200)])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_folded_attention_matches_projected_attention(ops, n_items, Lq, Lk, E, u_is, u_rs, p):
     """K/V-folded few-query attention == nn.MultiheadAttention math with explicit K/V projections (fp64),
