@@ -205,8 +205,8 @@ int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const fl
  * c_amax (nullable): a zeroed max|x| record (64 floats) that receives max|C| of the values as stored (after the whole epilogue,
  * `accumulate` included), so the next GEMM that takes C as its gradient operand needs no pass of its own; a split-K launch
  * (atomics) cannot know it and returns 2 with the record untouched.
- * Tile height: 256 rows, or 192 for row-form A operands when that fills the last round of the persistent walk better
- * (QT_PS_WMT=3|4 in the environment pins it). */
+ * Tile height: 256 rows, or 192 / 128 for row-form A operands when the launcher's cost model finds that the shorter tile fills the
+ * rounds of the persistent walk better (QT_PS_WMT=2|3|4 in the environment pins it). */
 int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
                const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,

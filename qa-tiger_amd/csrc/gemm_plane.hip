@@ -99,8 +99,8 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
     if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
     constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
-    static_assert((NWM == 2 && (WMT == 4 || (WMT == 3 && !AKS && FMT == 0))) || (NWM == 4 && WMT == 2 && FMT == 0),
-                  "tile shapes: 8 waves x (128|96) x 64, or 16 waves x 64 x 64");
+    static_assert((NWM == 2 && (WMT == 4 || ((WMT == 3 || WMT == 2) && !AKS && FMT == 0))) || (NWM == 4 && WMT == 2 && FMT == 0),
+                  "tile shapes: 8 waves x (128|96|64) x 64, or 16 waves x 64 x 64");
     constexpr int WNT = 2, NWN = 4;                   // wave tile (32 WMT) x 64 = WMT x 2 MFMA tiles of 32 x 32
     constexpr int BM = NWM * WMT * 32, BN = 256, GM = 4;
     constexpr int NBP = 32 / (NWM * NWN);              // 1 KiB DMA pieces of the B tile per wave (A: WMT per wave)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
             if (t > 0 && t + 1 < nk) {
                 if constexpr (WMT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if constexpr (WMT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // (always: the pieces of A(t+1) are the youngest transfers)
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
@@ -361,14 +361,14 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
             const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
             auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), then the WMT pieces of A(t+2) — this order is what vmcnt(WMT) counts on
                 constexpr int seg = decltype(SEG)::value;
-                if constexpr (seg < NBP) { if (do_b) dma_b1(kb1, stb, seg); }
-                else {
-                    if (do_a) dma_a1(ka2, sta, seg - NBP);
-                    if constexpr (seg == NS - 1) {             // 192-row tile: 6 segments carry 4 + 3 pieces, the last one two
-#pragma unroll
-                        for (int e = NS - NBP; e < WMT; ++e) if (do_a) dma_a1(ka2, sta, e);
+                constexpr int NP = NBP + WMT;                  // pieces per wave per step, spread evenly over the NS segments in this order
+                p_static_for<NP>([&](auto PC) {
+                    constexpr int pc = decltype(PC)::value;
+                    if constexpr ((pc * NS) / NP == seg) {
+                        if constexpr (pc < NBP) { if (do_b) dma_b1(kb1, stb, pc); }
+                        else { if (do_a) dma_a1(ka2, sta, pc - NBP); }
                     }
-                }
+                });
             };
             if (!(p.debug & 4)) {
                 if constexpr (FMT == 1) compute8((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
@@ -872,22 +872,22 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     const long ovh = 16;
     int force_wmt = 0;                                   // QT_PS_WMT=3|4 pins the tile height (tests, A/B runs); read per call
     { const char* e = getenv("QT_PS_WMT"); if (e) force_wmt = atoi(e); }
-    const bool wmt3_ok = fmt == 0 && !a_kslow && force_wmt != 4;
+    const bool wmt3_ok = fmt == 0 && !a_kslow && force_wmt != 4;      // the 192- and 128-row tiles: row-form fp16 A operands
     int wmt = 4;
     {
         const bool fixed_split = split_k > 0;
         long best = -1;
         int best_s = fixed_split ? split_k : 1;
-        for (int cand = 4; cand >= 3; --cand) {
-            if (cand == 3 && !wmt3_ok) break;
-            if (cand == 4 && force_wmt == 3 && wmt3_ok) continue;
+        for (int cand = 4; cand >= 2; --cand) {
+            if (cand < 4 && !wmt3_ok) break;
+            if (force_wmt >= 2 && force_wmt <= 4 && wmt3_ok && cand != force_wmt) continue;
             const long tl = (long)((M + 64 * cand - 1) / (64 * cand)) * tiles_n;
             long maxs = 1;
             if (!fixed_split && plain_epilogue && tl < 2 * slots && K >= 16 * KS) { maxs = K / (4 * KS); if (maxs > 64) maxs = 64; }
             for (long s = fixed_split ? split_k : 1; s <= (fixed_split ? split_k : maxs); ++s) {
                 const long rounds = (tl * s + slots - 1) / slots;
                 const long ksteps = ((K + s - 1) / s + KS - 1) / KS;
-                long cost = rounds * (ksteps + ovh) * (cand == 4 ? 100 : 79);      // 79 = 75 x 1.05
+                long cost = rounds * (ksteps + ovh) * (cand == 4 ? 100 : (cand == 3 ? 79 : 58));      // 75 x 1.05, 50 x 1.16: shorter tiles reuse B less
                 // split-K pays for its fp32 atomics at the L2's rate (measured: ~270 per ns for the whole chip = 513e3 per K-step time
                 // of 1.9 us) plus the zeroing launch and the drain (~20 us): tools/sweep_splitk.py
                 if (s > 1) cost += (long)(((double)s * M * N / 513e3 + 10.0) * 100.0);
@@ -921,7 +921,8 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
         QT_PS_ATTR(false, false, true, 0); QT_PS_ATTR(false, true, true, 0); QT_PS_ATTR(true, false, true, 0); QT_PS_ATTR(true, true, true, 0);
         QT_PS_ATTR(false, false, false, 1); QT_PS_ATTR(false, false, true, 1);
 #undef QT_PS_ATTR
-#define QT_PS_ATTR3(BK_, SW_) (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, BK_, SW_, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+#define QT_PS_ATTR3(BK_, SW_) (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, BK_, SW_, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                              (void)hipFuncSetAttribute((const void*)qt_gemm_ps_kernel<false, BK_, SW_, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
         QT_PS_ATTR3(false, false); QT_PS_ATTR3(false, true); QT_PS_ATTR3(true, false); QT_PS_ATTR3(true, true);
 #undef QT_PS_ATTR3
         ps_attr_done = true;
@@ -936,16 +937,23 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
         if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<false, BK_, true, 0, 3>), grid, dim3(512), lds, st, a);  \
         else hipLaunchKernelGGL((qt_gemm_ps_kernel<false, BK_, false, 0, 3>), grid, dim3(512), lds, st, a);      \
     } while (0)
+#define QT_PS2(BK_)                                                                                           \
+    do {                                                                                                      \
+        if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<false, BK_, true, 0, 2>), grid, dim3(512), lds, st, a);  \
+        else hipLaunchKernelGGL((qt_gemm_ps_kernel<false, BK_, false, 0, 2>), grid, dim3(512), lds, st, a);      \
+    } while (0)
     if (fmt == 1) {
         if (swap) hipLaunchKernelGGL((qt_gemm_ps_kernel<false, false, true, 1>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((qt_gemm_ps_kernel<false, false, false, 1>), grid, dim3(512), lds, st, a);
     } else if (wmt == 3) { if (b_kslow) QT_PS3(true); else QT_PS3(false); }
+    else if (wmt == 2) { if (b_kslow) QT_PS2(true); else QT_PS2(false); }
     else if (!a_kslow && !b_kslow) QT_PS(false, false);
     else if (!a_kslow && b_kslow) QT_PS(false, true);
     else if (a_kslow && !b_kslow) QT_PS(true, false);
     else QT_PS(true, true);
 #undef QT_PS
 #undef QT_PS3
+#undef QT_PS2
     QT_CHECK_LAUNCH(who);
     return (c_amax && split_k > 1) ? 2 : QT_OK;
 }

@@ -97,7 +97,7 @@ def test_gemm_ps_split_k_and_epilogues(ops):
     assert torch.equal(d1 == 0, d2 == 0) and rel(d1, d2) < 1e-5
 
 
-@pytest.mark.parametrize('wmt', [3, 4])
+@pytest.mark.parametrize('wmt', [2, 3, 4])
 def test_gemm_ps_both_tile_heights(ops, wmt, monkeypatch):
     """The launcher picks the 192-row (WMT 3) or the 256-row (WMT 4) tile by its cost model; QT_PS_WMT pins it.  Row-form A
     operands on both heights: ragged M, several rounds of the persistent walk (> 256 tiles), the dX orientation, every epilogue,
