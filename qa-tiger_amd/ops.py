@@ -550,6 +550,7 @@ class GradLink:
 # below this many rows a Linear stays on the split-in-the-consumer kernels: a handful of 256x256 tiles leaves the chip idle and
 # the operand passes are pure launch latency there (measured: 256-row layers 28 us on qt_gemm_ps vs 17 us on qt_gemm_x3's 64-row tiles)
 plane_min_rows = int(_os.environ.get('QT_PLANE_MIN_ROWS', '2048'))
+plane_dw_min_rows = int(_os.environ.get('QT_PLANE_DW_MIN_ROWS', '8192'))    # below: forward and dX on the pre-split kernel, dW on the small-tile kernel
 
 
 def _plane_ok(rows: int, n_out: int, k_in: int) -> bool:
@@ -716,8 +717,11 @@ class LinearFn(torch.autograd.Function):
                      a_amax=xam, b_amax=wam)
             ctx.wam = wam
             ctx.xam = xam                                # robust-range mode: the dW GEMM scales the saved input by the same record
-        # the plane path saves the input's IMAGE (same bytes) for the dW GEMM, not the fp32 rows
-        ctx.save_for_backward(x2 if ximg is None else ximg.data, weight, y if relu else None)
+        # the plane path saves the input's IMAGE (same bytes) for the dW GEMM, not the fp32 rows — unless the layer has so few rows
+        # that its dW (a 768-wide output over a short K) is quicker on the small-tile split-K kernel, which reads fp32 (measured at the
+        # 8-GPU shard, K = 3840: 49 us against 67-74 us; tools/sweep_splitk.py)
+        ctx.dw_on_image = ximg is not None and x2.shape[0] >= plane_dw_min_rows
+        ctx.save_for_backward(x2 if (ximg is None or not ctx.dw_on_image) else ximg.data, weight, y if relu else None)
         ctx.used_plane = ximg is not None
         if ximg is not None:
             ctx.xam = ximg.amax                          # None unless the robust-range mode scaled the input's image
@@ -749,7 +753,7 @@ class LinearFn(torch.autograd.Function):
             if bgv is not None:
                 db = _grad_written(b_param, bgv)
             wimg = ctx.wimg
-            ximg = SplitImage(x2, x2.shape[0], x2.shape[1], ctx.xam)
+            ximg = SplitImage(x2, x2.shape[0], x2.shape[1], ctx.xam) if ctx.dw_on_image else None
             if ctx.needs_input_grad[0]:
                 # max|dX| is measured by the epilogue that stores it and rides on the tensor autograd hands to dX's consumer
                 cam = new_amax(g.device)
@@ -770,10 +774,14 @@ class LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 wgv = _claim_grad_view(w_param)
                 # a claimed slice of the zeroed flat gradient buffer is accumulated into: no zeroing launch in front of a split-K GEMM
-                dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:],
-                             accumulate=wgv is not None and grads_prezeroed)
-                if dw is None:
-                    raise _lib.QTError('qt_gemm_ps refused a dW shape its forward accepted')
+                if ctx.dw_on_image:
+                    dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:],
+                                 accumulate=wgv is not None and grads_prezeroed)
+                    if dw is None:
+                        raise _lib.QTError('qt_gemm_ps refused a dW shape its forward accepted')
+                else:
+                    dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_amax=gimg.amax, b_amax=ctx.xam,
+                              out=None if wgv is None else wgv[:], accumulate=wgv is not None and grads_prezeroed)
                 if wgv is not None:
                     dw = _grad_written(w_param, wgv)
         else:
