@@ -244,16 +244,31 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int w
     const int Lq = p.Lq, Lk = p.Lk;
     float* Ks = lds + pl * (2 * KR * LDK);
     float* Vs = Ks + KR * LDK;
-    for (int idx = wip * 64 + lane; idx < KR * V4; idx += wpp * 64) {
-        const int j = idx / V4, c4 = idx - j * V4;
-        float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-        if (active && j < Lk) {
-            const long row = (long)kvn * p.kv_is + j;
-            kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
-            vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+    {   // K|V fill with all trips of loads in flight before the first LDS store (as in the backward): 14x14 launch 0.545 -> 0.466 ms
+        constexpr int FU = 6;
+        for (int base = wip * 64 + lane; base < KR * V4; base += FU * wpp * 64) {
+            float4 kk[FU], vv[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * wpp * 64;
+                const int j = idx / V4, c4 = idx - j * V4;
+                kk[u] = make_float4(0.f, 0.f, 0.f, 0.f); vv[u] = kk[u];
+                if (active && idx < KR * V4 && j < Lk) {
+                    const long row = (long)kvn * p.kv_is + j;
+                    kk[u] = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
+                    vv[u] = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * wpp * 64;
+                if (idx < KR * V4) {
+                    const int j = idx / V4, c4 = idx - j * V4;
+                    *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk[u];
+                    *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv[u];
+                }
+            }
         }
-        *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk;
-        *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv;
     }
     __syncthreads();
     if (!active) return;
@@ -368,16 +383,32 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
     for (int rep = 0; rep < reps; ++rep) {
         const int n = first + rep * p.n_kv;
         __syncthreads();                                                // previous phase B done with Q|dO and PT|ST
-        for (int idx = wip * 64 + lane; idx < Lk * V4; idx += wpp * 64) {
-            const int j = idx / V4, c4 = idx - j * V4;
-            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-            if (active) {
-                const long row = (long)kvn * p.kv_is + j;
-                kk = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
-                vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+        // (several trips of loads in flight before the first LDS store: one trip at a time exposed a global-load latency per trip,
+        // ~6 trips for K|V and 6 for Q|dO per problem.  Also tried: requesting the wave's q / dO fragments of phase A before this
+        // fill — the 48 extra live registers cost the 14x14 launch its third workgroup per CU: 1.23 -> 1.65 ms)
+        constexpr int FU = 3;
+        for (int base = wip * 64 + lane; base < Lk * V4; base += FU * wpp * 64) {
+            float4 kk[FU], vv[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * wpp * 64;
+                kk[u] = make_float4(0.f, 0.f, 0.f, 0.f); vv[u] = kk[u];
+                if (active && idx < Lk * V4) {
+                    const int j = idx / V4, c4 = idx - j * V4;
+                    const long row = (long)kvn * p.kv_is + j;
+                    kk[u] = *reinterpret_cast<const float4*>(p.k + row * p.ldk + hd * DH + c4 * 4);
+                    vv[u] = *reinterpret_cast<const float4*>(p.v + row * p.ldv + hd * DH + c4 * 4);
+                }
             }
-            *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk;
-            *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv;
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * wpp * 64;
+                if (idx < Lk * V4) {
+                    const int j = idx / V4, c4 = idx - j * V4;
+                    *reinterpret_cast<float4*>(Ks + j * LDK + c4 * 4) = kk[u];
+                    *reinterpret_cast<float4*>(Vs + j * LDK + c4 * 4) = vv[u];
+                }
+            }
         }
         __syncthreads();
         // ---------------- phase A: one wave per 16-query tile
@@ -485,15 +516,27 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
             }
         }
         __syncthreads();                                                // K|V dead; PT|ST complete
-        for (int idx = wip * 64 + lane; idx < Lq * V4; idx += wpp * 64) {
-            const int qi = idx / V4, c4 = idx - qi * V4;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
-            if (active) {
-                t = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)qi * p.q_rs) * p.ldq + hd * DH + c4 * 4);
-                u = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)qi * p.do_rs) * p.lddo + hd * DH + c4 * 4);
+        for (int base = wip * 64 + lane; base < Lq * V4; base += FU * wpp * 64) {
+            float4 tq[FU], tg[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * wpp * 64;
+                tq[u] = make_float4(0.f, 0.f, 0.f, 0.f); tg[u] = tq[u];
+                if (active && idx < Lq * V4) {
+                    const int qi = idx / V4, c4 = idx - qi * V4;
+                    tq[u] = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)qi * p.q_rs) * p.ldq + hd * DH + c4 * 4);
+                    tg[u] = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)qi * p.do_rs) * p.lddo + hd * DH + c4 * 4);
+                }
             }
-            *reinterpret_cast<float4*>(Qs + qi * LDK + c4 * 4) = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);
-            *reinterpret_cast<float4*>(Gs + qi * LDK + c4 * 4) = u;
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * wpp * 64;
+                if (idx < Lq * V4) {
+                    const int qi = idx / V4, c4 = idx - qi * V4;
+                    *reinterpret_cast<float4*>(Qs + qi * LDK + c4 * 4) = make_float4(tq[u].x * p.scale, tq[u].y * p.scale, tq[u].z * p.scale, tq[u].w * p.scale);
+                    *reinterpret_cast<float4*>(Gs + qi * LDK + c4 * 4) = tg[u];
+                }
+            }
         }
         __syncthreads();
         // ---------------- phase B: one wave per 16-key tile; MFMA k dimension = query index
