@@ -63,11 +63,22 @@ __device__ inline void xa_reduce4(float (&v)[4], int lane) {
 }
 
 __device__ inline void xa_stage_rows(const float* __restrict__ xbase, float* __restrict__ Xs, int r0, int nrows, int Lk, int D, int nv) {
-    for (int idx = threadIdx.x; idx < nrows * nv; idx += XA_NT) {
-        const int r = idx / nv, c4 = idx - r * nv;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + r < Lk) v = *reinterpret_cast<const float4*>(xbase + (long)(r0 + r) * D + c4 * 4);
-        *reinterpret_cast<float4*>(Xs + r * D + c4 * 4) = v;
+    constexpr int U = 4;                                           // trips of loads in flight before the first LDS store
+    for (int base = threadIdx.x; base < nrows * nv; base += U * XA_NT) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * XA_NT;
+            const int r = idx / nv, c4 = idx - r * nv;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < nrows * nv && r0 + r < Lk) v[u] = *reinterpret_cast<const float4*>(xbase + (long)(r0 + r) * D + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * XA_NT;
+            const int r = idx / nv, c4 = idx - r * nv;
+            if (idx < nrows * nv) *reinterpret_cast<float4*>(Xs + r * D + c4 * 4) = v[u];
+        }
     }
 }
 
@@ -193,11 +204,22 @@ __global__ __launch_bounds__(XA_NT, 2) void qt_xattn_fwd_mfma_kernel(XAttnArgs p
     auto urow_of = [&](int qh) { const int qq = min(qh, NQ - 1); const int i = qq / p.H, h = qq - i * p.H;
                                  return ((long)n * p.u_is + (long)i * p.u_rs) * p.H + h; };
     // stage the key rows (zero rows past Lk)
-    for (int idx = tid; idx < 16 * (D / 4); idx += XA_NT) {
-        const int row = idx / (D / 4), c4 = idx - row * (D / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < Lk) v = *reinterpret_cast<const float4*>(xbase + (long)row * D + c4 * 4);
-        *reinterpret_cast<float4*>(Xs + row * XS + c4 * 4) = v;
+    {   // all trips of loads in flight before the first LDS store (one trip at a time exposed a global-load latency per trip)
+        constexpr int TR = (16 * (D / 4) + XA_NT - 1) / XA_NT;
+        float4 v[TR];
+#pragma unroll
+        for (int u = 0; u < TR; ++u) {
+            const int idx = tid + u * XA_NT;
+            const int row = idx / (D / 4), c4 = idx - row * (D / 4);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < 16 * (D / 4) && row < Lk) v[u] = *reinterpret_cast<const float4*>(xbase + (long)row * D + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < TR; ++u) {
+            const int idx = tid + u * XA_NT;
+            const int row = idx / (D / 4), c4 = idx - row * (D / 4);
+            if (idx < 16 * (D / 4)) *reinterpret_cast<float4*>(Xs + row * XS + c4 * 4) = v[u];
+        }
     }
     // partial scores over this wave's columns
     xa_f4 sacc = {0.f, 0.f, 0.f, 0.f};
