@@ -118,16 +118,18 @@ __global__ __launch_bounds__(256) void qt_moe_csum_kernel(const float* __restric
     csum[idx] = s;
 }
 
-// grid = S*B blocks; H [(S*B*T), K*Dh]; R [S*B, K*Dh]
+// grid = (S*B, column chunks of 256 float4) blocks (one block per sample put a single workgroup on each CU: 1.8 TB/s); H [(S*B*T), K*Dh]; R [S*B, K*Dh]
 __global__ __launch_bounds__(256) void qt_moe_treduce_fwd_kernel(
     const float* __restrict__ H, const float* __restrict__ coef, int B, int T, int K, int Dh,
     float* __restrict__ R) {
     const int sb = blockIdx.x, b = sb % B;
     const int nv = (K * Dh) >> 2, dv = Dh >> 2;
-    for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
+    const int c4 = blockIdx.y * 256 + threadIdx.x;
+    if (c4 < nv) {
         const int e = c4 / dv;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < T; ++t) {
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) {                        // (same summation order over t as before: bitwise the same result)
             const float w = coef[((long)b * T + t) * K + e];
             const float4 h = *reinterpret_cast<const float4*>(H + ((long)sb * T + t) * (long)(K * Dh) + c4 * 4);
             acc.x = fmaf(w, h.x, acc.x); acc.y = fmaf(w, h.y, acc.y); acc.z = fmaf(w, h.z, acc.z); acc.w = fmaf(w, h.w, acc.w);
@@ -288,7 +290,7 @@ extern "C" int qt_moe_treduce_fwd(void* stream, const float* H, const float* coe
     QT_CHECK_ARG(H && coef && R, "qt_moe_treduce_fwd: null pointer");
     QT_CHECK_ARG(S > 0 && B > 0 && T > 0 && K > 0 && Dh > 0 && Dh % 4 == 0, "qt_moe_treduce_fwd: Dh=%d must be a multiple of 4", Dh);
     QT_CHECK_ARG(qt_aligned16(H) && qt_aligned16(R), "qt_moe_treduce_fwd: alignment");
-    hipLaunchKernelGGL(qt_moe_treduce_fwd_kernel, dim3(S * B), dim3(256), 0, (hipStream_t)stream, H, coef, B, T, K, Dh, R);
+    hipLaunchKernelGGL(qt_moe_treduce_fwd_kernel, dim3(S * B, ((K * Dh >> 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, coef, B, T, K, Dh, R);
     QT_CHECK_LAUNCH("qt_moe_treduce_fwd");
     return QT_OK;
 }
