@@ -99,3 +99,25 @@ def test_fused_adam_is_a_torch_optimizer(qt, synth):
     net.double()
     with pytest.raises(RuntimeError, match='flat buffer'):
         flat.check()
+
+
+def test_integration_md_binding_stubs_run_as_written():
+    """The ctypes stubs of INTEGRATION.md section 3 (`linear` on qt_gemm_x3, `image` + `linear_ps` on qt_split_f16 / qt_gemm_ps),
+    executed verbatim from the document against libqatiger_hip.so with nothing of this repo's Python in between: a maintainer's
+    binding of the C ABI gives torch's result."""
+    import re
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    block = re.search(r"```python\nimport ctypes as C, torch\n(.*?)```", text, re.S)
+    assert block, 'INTEGRATION.md: the binding stub moved'
+    src = 'import ctypes as C, torch\n' + block.group(1).replace("C.CDLL('qa-tiger_amd/libqatiger_hip.so')", f"C.CDLL({os.path.join(REPO, 'qa-tiger_amd', 'libqatiger_hip.so')!r})")
+    import importlib
+    importlib.import_module('qa-tiger_amd._lib').build()            # (the library itself; the stub binds it on its own)
+    ns = {}
+    exec(compile(src, 'INTEGRATION.md', 'exec'), ns)
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(2304, 768, generator=g).cuda(), torch.randn(512, 768, generator=g).cuda(), torch.randn(512, generator=g).cuda()
+    ref = (x.double() @ w.double().t() + b.double())
+    y = ns['linear'](x, w, b)
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    y2 = ns['linear_ps'](ns['image'](x), ns['image'](w), b, 2304, 512, 768)
+    assert float((y2.double() - ref).abs().max() / ref.abs().max()) < 2e-6
