@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int w
             }
         }
     }
-    __syncthreads();
+    if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order
     if (!active) return;
     for (int q0 = wip * 16; q0 < Lq; q0 += wpp * 16) {
         const int q = q0 + c;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
     float gmax = 0.f;                                                   // max |gradient| this thread writes (g_amax)
     for (int rep = 0; rep < reps; ++rep) {
         const int n = first + rep * p.n_kv;
-        __syncthreads();                                                // previous phase B done with Q|dO and PT|ST
+        if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order                                                // previous phase B done with Q|dO and PT|ST
         // (several trips of loads in flight before the first LDS store: one trip at a time exposed a global-load latency per trip,
         // ~6 trips for K|V and 6 for Q|dO per problem.  Also tried: requesting the wave's q / dO fragments of phase A before this
         // fill — the 48 extra live registers cost the 14x14 launch its third workgroup per CU: 1.23 -> 1.65 ms)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                 }
             }
         }
-        __syncthreads();
+        if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order
         // ---------------- phase A: one wave per 16-query tile
         for (int q0 = wip * 16; q0 < QR; q0 += wpp * 16) {
             const int q = q0 + c;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                 }
             }
         }
-        __syncthreads();                                                // K|V dead; PT|ST complete
+        if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order                                                // K|V dead; PT|ST complete
         for (int base = wip * 64 + lane; base < Lq * V4; base += FU * wpp * 64) {
             float4 tq[FU], tg[FU];
 #pragma unroll
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
                 }
             }
         }
-        __syncthreads();
+        if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order
         // ---------------- phase B: one wave per 16-key tile; MFMA k dimension = query index
         for (int kt = wip; kt * 16 < Lk; kt += wpp) {
             floatx4v av[DC], ak[DC];
