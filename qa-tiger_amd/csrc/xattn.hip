@@ -187,62 +187,50 @@ __global__ __launch_bounds__(XA_NT) void qt_xattn_fwd_kernel(XAttnArgs p) {
 //   * the probabilities go through a 1 KiB per-wave LDS tile into operand layout, and the context block of the wave's columns is
 //     computed TRANSPOSED (A = X^T from the LDS-staged rows, B = P^T): a lane ends up with four consecutive columns of one
 //     (query, head) row -> 16-byte stores.
-// LDS: the item's key rows row-major with a 16-float skew (conflict-free 4-byte operand reads), 67 KiB at D = 768: two workgroups per CU.
+// No row is staged in LDS (the wave's column blocks of the key rows stay in registers): 25 KiB per workgroup.
 typedef float xa_f4 __attribute__((ext_vector_type(4)));
 template <int DB>      // 16-column blocks per wave: D = 128 * DB
-__global__ __launch_bounds__(XA_NT, 2) void qt_xattn_fwd_mfma_kernel(XAttnArgs p) {
+__global__ __launch_bounds__(XA_NT, 3) void qt_xattn_fwd_mfma_kernel(XAttnArgs p) {
     if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
-    constexpr int D = 128 * DB, XS = D + 16;
+    constexpr int D = 128 * DB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Xs = lds;                                   // [16][XS]
-    float* Sp = Xs + 16 * XS;                          // [8][16][16] partial score tiles
-    float* Pw = Sp + 8 * 256;                          // [8][16][17] probabilities, one tile per wave
+    float* Sp = lds;                                   // [8][16][16] partial score tiles
+    float* Pw = Sp + 8 * 256;                          // per wave: P [16][17], T [16][17] (transpose scratch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int n = blockIdx.x, NQ = p.Lq * p.H, Lk = p.Lk;
     const float* xbase = p.x + (long)n * Lk * D;
     auto urow_of = [&](int qh) { const int qq = min(qh, NQ - 1); const int i = qq / p.H, h = qq - i * p.H;
                                  return ((long)n * p.u_is + (long)i * p.u_rs) * p.H + h; };
-    // stage the key rows (zero rows past Lk)
-    {   // all trips of loads in flight before the first LDS store (one trip at a time exposed a global-load latency per trip)
-        constexpr int TR = (16 * (D / 4) + XA_NT - 1) / XA_NT;
-        float4 v[TR];
-#pragma unroll
-        for (int u = 0; u < TR; ++u) {
-            const int idx = tid + u * XA_NT;
-            const int row = idx / (D / 4), c4 = idx - row * (D / 4);
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < 16 * (D / 4) && row < Lk) v[u] = *reinterpret_cast<const float4*>(xbase + (long)row * D + c4 * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < TR; ++u) {
-            const int idx = tid + u * XA_NT;
-            const int row = idx / (D / 4), c4 = idx - row * (D / 4);
-            if (idx < 16 * (D / 4)) *reinterpret_cast<float4*>(Xs + row * XS + c4 * 4) = v[u];
-        }
-    }
-    // partial scores over this wave's columns
+    // partial scores over this wave's columns; the key rows of those columns stay in registers for the context product
+    // (no row is staged in LDS: 10 KiB per workgroup instead of 67, the key rows are read from memory exactly once per item)
+    float4 xb[DB];
     xa_f4 sacc = {0.f, 0.f, 0.f, 0.f};
     {
         const float* up = p.u + urow_of(r16) * D + 4 * kq;
         const float* xp = xbase + (long)min(r16, Lk - 1) * D + 4 * kq;
         const bool uok = r16 < NQ, xok = r16 < Lk;
+        float4 ua[DB];
 #pragma unroll
         for (int b = 0; b < DB; ++b) {
             const int cb = (wave * DB + b) * 16;
-            const float4 ua = uok ? *reinterpret_cast<const float4*>(up + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 xb = xok ? *reinterpret_cast<const float4*>(xp + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.x, xb.x, sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.y, xb.y, sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.z, xb.z, sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.w, xb.w, sacc, 0, 0, 0);
+            ua[b] = uok ? *reinterpret_cast<const float4*>(up + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xb[b] = xok ? *reinterpret_cast<const float4*>(xp + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].x, xb[b].x, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].y, xb[b].y, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].z, xb[b].z, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[b].w, xb[b].w, sacc, 0, 0, 0);
         }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) Sp[wave * 256 + (4 * kq + reg) * 16 + r16] = sacc[reg];
     __syncthreads();
     // full tile in every wave: key = r16 on the lane, (query, head) rows 4 kq + reg in registers
-    float* Pm = Pw + wave * (16 * 17);
+    float* Pm = Pw + wave * (2 * 16 * 17);
+    float* Tm = Pm + 16 * 17;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int qh = 4 * kq + reg;
@@ -274,9 +262,11 @@ __global__ __launch_bounds__(XA_NT, 2) void qt_xattn_fwd_mfma_kernel(XAttnArgs p
 #pragma unroll
     for (int b = 0; b < DB; ++b) {
         const int cb = (wave * DB + b) * 16;
+        // A = X^T of the block: a 16 x 16 register transpose through the wave's LDS tile (lane (key r16, kq) holds x[key][cb + 4 kq ..])
+        Tm[r16 * 17 + 4 * kq + 0] = xb[b].x; Tm[r16 * 17 + 4 * kq + 1] = xb[b].y; Tm[r16 * 17 + 4 * kq + 2] = xb[b].z; Tm[r16 * 17 + 4 * kq + 3] = xb[b].w;
         xa_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(4 * j + kq) * XS + cb + r16], pb[j], acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Tm[(4 * j + kq) * 17 + r16], pb[j], acc, 0, 0, 0);
         if (r16 < NQ) *reinterpret_cast<float4*>(p.ctx + ur16 * D + cb + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
@@ -644,7 +634,7 @@ extern "C" int qt_xattn_fwd(void* stream, const float* u, long u_is, long u_rs, 
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.seed = seed; a.salt = qt_salt_ptr;
     hipStream_t st = (hipStream_t)stream;
     if (Lq * H <= 16 && Lk <= 16 && (D == 768 || D == 1024)) {      // the PatchSelecter shape class: both products on the f32 MFMA
-        const size_t mlds = sizeof(float) * ((size_t)16 * (D + 16) + 8 * 256 + 8 * 16 * 17);
+        const size_t mlds = sizeof(float) * ((size_t)8 * 256 + 8 * 2 * 16 * 17);
         static bool attr6 = false, attr8 = false;
         if (D == 768) {
             if (!attr6) { (void)hipFuncSetAttribute((const void*)qt_xattn_fwd_mfma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); attr6 = true; }
