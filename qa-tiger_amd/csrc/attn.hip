@@ -350,8 +350,10 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int w
     }
 }
 
+// (second launch-bound: waves per SIMD the register allocation must leave room for — three one-wave problems per SIMD for the 14x14
+// launch, two workgroups per CU for the multi-wave shapes; unconstrained, the compiler spent 177 resp. > 256 registers per lane)
 template <int DC, int NKT>
-__global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int wpp, int nqt) {
+__global__ __launch_bounds__(256, NKT == 1 ? 3 : (NKT <= 4 ? 2 : 1)) void qt_attn_bwd_mfma_kernel(AttnArgs p, int wpp, int nqt) {
     if (p.salt && p.drop_p > 0.f) p.seed += *p.salt;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DH = DC * 16, LDK = DH + 4, KR = NKT * 16, V4 = DH / 4;
@@ -411,6 +413,24 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
             }
         }
         if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order
+        // Multi-wave problems (NKT > 1: the AVQ shapes) have registers to spare (one or two workgroups per CU by LDS): the Q|dO rows
+        // that phase B will need in LDS are requested NOW and parked in registers across phase A, so their latency hides behind
+        // phase A's MFMAs instead of sitting between the two phases.  (Not for the 14x14 launch: there registers decide occupancy.)
+        constexpr bool PF = false && NKT > 1;   // (measured: with the registers this costs, the multi-wave shapes spill)
+        constexpr int QTR = PF ? (64 * V4 + 255) / 256 : 1;
+        float4 pq[QTR], pg[QTR];
+        if constexpr (PF) {
+#pragma unroll
+            for (int u = 0; u < QTR; ++u) {
+                const int idx = wip * 64 + lane + u * wpp * 64;
+                pq[u] = make_float4(0.f, 0.f, 0.f, 0.f); pg[u] = pq[u];
+                if (active && idx < Lq * V4) {
+                    const int qi = idx / V4, c4 = idx - qi * V4;
+                    pq[u] = *reinterpret_cast<const float4*>(p.q + ((long)n * p.q_is + (long)qi * p.q_rs) * p.ldq + hd * DH + c4 * 4);
+                    pg[u] = *reinterpret_cast<const float4*>(p.d_o + ((long)n * p.do_is + (long)qi * p.do_rs) * p.lddo + hd * DH + c4 * 4);
+                }
+            }
+        }
         // ---------------- phase A: one wave per 16-query tile
         for (int q0 = wip * 16; q0 < QR; q0 += wpp * 16) {
             const int q = q0 + c;
@@ -516,6 +536,17 @@ __global__ __launch_bounds__(256) void qt_attn_bwd_mfma_kernel(AttnArgs p, int w
             }
         }
         if (wpp > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();   // one wave per problem: its LDS region is private, LDS ops of a wave execute in order                                                // K|V dead; PT|ST complete
+        if constexpr (PF) {
+#pragma unroll
+            for (int u = 0; u < QTR; ++u) {
+                const int idx = wip * 64 + lane + u * wpp * 64;
+                if (idx < Lq * V4) {
+                    const int qi = idx / V4, c4 = idx - qi * V4;
+                    *reinterpret_cast<float4*>(Qs + qi * LDK + c4 * 4) = make_float4(pq[u].x * p.scale, pq[u].y * p.scale, pq[u].z * p.scale, pq[u].w * p.scale);
+                    *reinterpret_cast<float4*>(Gs + qi * LDK + c4 * 4) = pg[u];
+                }
+            }
+        } else
         for (int base = wip * 64 + lane; base < Lq * V4; base += FU * wpp * 64) {
             float4 tq[FU], tg[FU];
 #pragma unroll
