@@ -403,6 +403,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops._amax_pool.cur = 0                          # the pool's zeroing kernel must be inside the capture
+        engine.flat.amax_epoch = engine.flat.img_epoch = None   # ... and so must the refresh of the weights' max|w| records and images
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss = self._captured_part()
