@@ -360,8 +360,8 @@ def test_training_soak_at_real_dims(qt, synth):
 def test_repeated_backward_with_unchanged_weights_is_stable(qt, synth):
     """Weights' max|w| records and split images are cached while the weights do not change (evaluation, gradient accumulation,
     a stock optimizer stepping every n-th batch).  The records of one backward pass come from a recycled pool; a cached record
-    must not live there (regression: after ~500 pooled records the cached weight scales were overwritten and every gradient
-    was off by 4e-3).  Twelve fwd+bwd passes cycle the pool more than once: the last gradients must equal the first."""
+    must not live there (a wrapped cursor would hand the cached slot to another tensor and the weight would be scaled by that
+    tensor's maximum).  Twelve fwd+bwd passes cycle a small pool several times: the last gradients must equal the first."""
     cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 16})
     model = qt.QA_TIGER(**cfg.model_kwargs())
     model.load_state_dict(synth.make_state_dict(cfg, 5), strict=True)
@@ -380,7 +380,7 @@ def test_repeated_backward_with_unchanged_weights_is_stable(qt, synth):
                 first = g.clone()
         d = float((g - first).norm() / first.norm())
         print(f'gradient drift over 12 passes with cached weight images: {d:.2e}')
-        assert d < 5e-4          # (the regression was 4e-3; two correct passes can differ by a flipped ReLU gate: ~3e-5 of the whole vector)
+        assert d < 5e-4          # (a weight scaled by another tensor's record is off by orders of magnitude; two correct passes can differ by a flipped ReLU gate: ~3e-5 of the whole vector)
     finally:
         qt.ops._AmaxPool.HALF = keep_half
         qt.ops._amax_pool.buf = None
