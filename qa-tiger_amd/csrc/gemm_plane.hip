@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
             if (!AKS) {                                          // rows pc*8 .. pc*8+7, one 128-B line each
                 const int row = pc * 8 + (lane >> 3);
                 const int sl = (lane & 7) ^ ((row >> 1) & 7);
-                offA[i] = (unsigned)((long)min(m0 + row, p.M - 1) * p.lda + sl * 16);
+                offA[i] = (unsigned)((long)(min(m0 + row, p.M - 1) - m0) * p.lda + sl * 16);      // relative to the tile's first row (a_tile)
             } else {                                             // k row pc, 1 KiB = 8 blocks of 32 columns
                 const int unit = (lane >> 2) ^ (pc & 3);
                 const int blk = min((m0 >> 5) + (unit >> 1), (p.M >> 5) - 1);
@@ -163,14 +163,16 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
             }
         }
     };
+    // Row-form A: the wave-uniform base moves with the tile (per-lane offsets are 32-bit: a gradient image of 537600 x 3072
+    // — BASELINE config 4 at B = 128 — is 6.6 GB), m0 is uniform and current whenever a DMA of this tile is issued.
     auto dma_a = [&](int k0, int stage) {
-        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 / KS) * 128;
+        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
         const unsigned la = lds0 + stage * P_OPER + wave * (WMT * 1024);
 #pragma unroll
         for (int i = 0; i < WMT; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
     auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
-        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)(k0 / KS) * 128;
+        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
         qt_dma16(lds0 + stage * P_OPER + wave * (WMT * 1024) + i * 1024, sa, offA[i]);
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
@@ -852,7 +854,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     if ((a_kslow && M % 32) || (b_kslow && N % 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: a K-slow operand needs its width to be a multiple of 32", who);
     if (M < 256 || N < 128) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: problem too small for the 256x256 tile", who);
     {   // per-lane source offsets are 32-bit byte offsets from a wave-uniform base
-        const long spanA = a_kslow ? 32 * lda_bytes + 4L * M : (long)M * lda_bytes;
+        const long spanA = a_kslow ? 32 * lda_bytes + 4L * M : 256L * lda_bytes;      // row-form A is addressed relative to its tile
         const long spanB = b_kslow ? 32 * ldb_bytes + 4L * N : (long)N * ldb_bytes;
         if (spanA >= (1L << 32) || spanB >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: operand spans more than 4 GiB", who);
     }

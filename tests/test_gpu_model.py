@@ -229,6 +229,36 @@ def test_config4_full_size_b128_invariances(qt, synth):
     assert float((out_p - base).abs().max()) / scale < 1e-4
 
 
+def test_config4_full_size_b128_backward(qt, synth):
+    """Config 4 at its full size, BACKWARD: 537600 patch rows, gradient images of up to 6.6 GB (537600 x 3072 fp32) — beyond the
+    32-bit per-lane offsets of the LDS-DMA loads unless the operand base moves with the tile (regression: the dX GEMM of the packed
+    in-projection was refused at this size and the step died).  No CPU oracle at this size (T = 300): the pre-split pipeline's
+    gradients are compared with the split-in-the-consumer kernels' (`ops.plane = False`: other kernels, other addressing, same
+    math), every parameter, at the gates of the other gradient tests."""
+    cfg = synth.CONFIG_4
+    model = build(qt, synth, cfg, 713)
+    inp = qt.synth.fast_device_inputs(cfg, DEV, seed=9)
+
+    def grads(plane):
+        keep = qt.ops.plane
+        qt.ops.plane = plane
+        try:
+            model.zero_grad(set_to_none=True)
+            qt.CrossEntropyLoss()(model(inp)['out'], inp['label']).backward()
+        finally:
+            qt.ops.plane = keep
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+    ga, gb = grads(True), grads(False)
+    errs = {n: float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-30)) for n in ga}
+    assert all(bool(torch.isfinite(g).all()) for g in ga.values())
+    print(f'config 4 (B=128) gradients, pre-split vs split-in-the-consumer: median {np.median(list(errs.values())):.2e}, worst {max(errs.values()):.2e}')
+    for n, e in errs.items():
+        assert e < GRAD_L2, (n, e)
+    assert float(np.median(list(errs.values()))) < GRAD_MEDIAN
+    del ga, gb
+    torch.cuda.empty_cache()
+
+
 def test_full_size_invariances(qt, synth):
     """Size-independent properties at B=256: the path has no positional term on patch
     tokens or words and no masks, so permuting them must not
