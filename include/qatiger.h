@@ -168,10 +168,15 @@ int qt_xent_fwd_bwd(void* stream, const float* logits, long ld, const long long*
  * (torch's L2 form, not AdamW). */
 int qt_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                  int step, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay);
-/* The same with the step count in DEVICE memory (a captured train step cannot take it as an argument): ++step_dev[0], the two bias
- * corrections go to bc_dev[0..1] (one-thread kernel), then the update reads them. */
+/* The same with everything that changes from step to step in DEVICE memory (a captured train step's kernel arguments are frozen):
+ * step_dev[0] = the step count, hp_dev[0..7] = { 1 - beta1^t, sqrt(1 - beta2^t), lr, beta1, beta2, eps, weight_decay, grad_scale }.
+ * qt_adam_set_dev writes the count and hp_dev[2..7] from host values; call it OUTSIDE the graph before every replay, so a learning-rate
+ * scheduler (StepLR / ReduceLROnPlateau, trainutils.py:147-182) or a loaded optimizer state reaches the replayed update.
+ * qt_adam_step_dev (inside the graph): ++step_dev[0], bias corrections into hp_dev[0..1] (one-thread kernel), then the update. */
+int qt_adam_set_dev(void* stream, long long* step_dev, float* hp_dev, long long step, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float grad_scale);
 int qt_adam_step_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                     long long* step_dev, float* bc_dev, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay);
+                     long long* step_dev, float* hp_dev);
 
 /* ---- pre-split operands (csrc/gemm_plane.hip): the same Linear / projection GEMMs and their backward, on operands whose
  * fp32 -> (hi, lo) fp16 split was done ONCE by a producer pass instead of inside every tile of the GEMM. ---- */

@@ -234,10 +234,13 @@ def qst_grounding(P, qst: Tensor, data: List[Tensor], ctx: _Ctx) -> Tensor:
 # QA_TIGER.forward (reference net.py:106-144)
 # --------------------------------------------------------------------------- #
 def qa_tiger_forward(P: Mapping[str, Tensor], inputs: Mapping[str, Tensor], K: int, k: int,
-                     train: bool = False, taps: Optional[dict] = None) -> Tensor:
+                     train: bool = False, taps: Optional[dict] = None, head_gate: Optional[Tensor] = None) -> Tensor:
     """inputs: audio [B,T,Da], video [B,T,Dv], patch [B,T,P,Dp], quest_feat [B,Dv],
     words_feat [B,L,Dv] (the two outputs of the frozen text tower, injected).
-    Returns logits [B,42]."""
+    Returns logits [B,42].
+    head_gate (tests only): a 0/1 mask [B,D] applied INSTEAD of the ReLU in front of the head (net.py:141).  The forward value is
+    continuous in a pre-activation at ~0 but the gradient is not; a test that compares gradients on a batch with a unit at its
+    threshold hands in the gate state the kernels took, after checking that it differs from the oracle's own only at such units."""
     ctx = _Ctx(train=train, taps=taps)
     audio = linear(P, 'audio_proj.proj', inputs['audio'])
     video = linear(P, 'video_proj.proj', inputs['video'])
@@ -259,7 +262,8 @@ def qa_tiger_forward(P: Mapping[str, Tensor], inputs: Mapping[str, Tensor], K: i
     ctx.tap('quest_grounding.1', fusion)
     fusion = qst_grounding(P, quest, [fusion[:, None, :], a_global], ctx)
     ctx.tap('quest_grounding.2', fusion)
-    return linear(P, 'head', torch.relu(fusion))                              # net.py:141-142
+    act = torch.relu(fusion) if head_gate is None else fusion * head_gate.to(fusion.dtype)
+    return linear(P, 'head', act)                                             # net.py:141-142
 
 
 def cross_entropy(logits: Tensor, label: Tensor) -> Tensor:
@@ -282,11 +286,11 @@ def adam_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], m: Dict[str, 
 
 
 def forward_backward(P: Dict[str, Tensor], inputs: Mapping[str, Tensor], K: int, k: int,
-                     train: bool = False, taps: Optional[dict] = None):
+                     train: bool = False, taps: Optional[dict] = None, head_gate: Optional[Tensor] = None):
     """One `train()` step body without the optimizer (reference trainutils.py:273-286).
     Returns (loss, logits, grads-by-name)."""
     leaves = {n: t.detach().clone().requires_grad_(True) for n, t in P.items()}
-    logits = qa_tiger_forward(leaves, inputs, K, k, train=train, taps=taps)
+    logits = qa_tiger_forward(leaves, inputs, K, k, train=train, taps=taps, head_gate=head_gate)
     loss = cross_entropy(logits, inputs['label'])
     loss.backward()
     grads = {n: (t.grad if t.grad is not None else torch.zeros_like(t)) for n, t in leaves.items()}

@@ -15,9 +15,9 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
-SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_plane.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
+SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_skinny.hip', 'gemm_plane.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
-ABI_VERSION = 204          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
+ABI_VERSION = 205          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
 FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     try:
         if not force and fresh():
             return LIB_PATH
-        return _build_locked(srcs, verbose)
+        return _build_locked(srcs, verbose, force)
     finally:
         fcntl.flock(lock, fcntl.LOCK_UN)
         lock.close()
@@ -65,7 +65,7 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
-def _build_locked(srcs, verbose: bool) -> str:
+def _build_locked(srcs, verbose: bool, force: bool = False) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     flags = FLAGS
     objdir = os.path.join(CSRC, '_obj')
@@ -79,11 +79,35 @@ def _build_locked(srcs, verbose: bool) -> str:
             obj = os.path.join(objdir, base + ('' if part is None else f'_p{part}') + '.o')
             jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-DQT_X3_PART={part}']), obj))
 
+    import hashlib
+    with open(os.path.join(CSRC, 'qt_common.h'), 'rb') as f:
+        common = f.read()
+
+    def obj_hash(cmd):
+        h = hashlib.sha256(' '.join(c for c in cmd if not c.endswith('.o')).encode())
+        h.update(common)
+        with open(cmd[cmd.index('-c') + 1], 'rb') as f:
+            h.update(f.read())
+        return h.hexdigest()
+
     def run(job):
-        cmd, _ = job
+        # one object per job, skipped when its source, the shared header and the command line are unchanged (force=True compiles all)
+        cmd, obj = job
+        want = obj_hash(cmd)
+        if not force and os.path.exists(obj):
+            try:
+                with open(obj + '.hash') as f:
+                    if f.read().strip() == want:
+                        return subprocess.CompletedProcess(cmd, 0, '', '')
+            except OSError:
+                pass
         if verbose:
             print(' '.join(cmd), file=sys.stderr)
-        return subprocess.run(cmd, capture_output=True, text=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode == 0:
+            with open(obj + '.hash', 'w') as f:
+                f.write(want + '\n')
+        return res
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
@@ -115,7 +139,8 @@ SIGNATURES = {
     'qt_zero_f32': [_p, _p, _l],
     'qt_set_dropout_salt': [_p],
     'qt_bump_dropout_salt': [_p, _p, _u64],
-    'qt_adam_step_dev': [_p, _p, _p, _p, _p, _l, _p, _p, _f, _f, _f, _f, _f, _f],
+    'qt_adam_step_dev': [_p, _p, _p, _p, _p, _l, _p, _p],
+    'qt_adam_set_dev': [_p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _f],
     'qt_amax_f32': [_p, _p, _l, _l, _i, _p, _i],
     'qt_amax_segments': [_p, _p, _p, _p, _i, _p],
     'qt_xattn_fwd': [_p, _p, _l, _l, _p, _i, _i, _i, _i, _i, _f, _f, _u64, _p, _p, _p],

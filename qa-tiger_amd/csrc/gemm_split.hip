@@ -516,6 +516,14 @@ QT_X3_DECL(qt_x3_small_3) { launch_x3<2, 2, 2, 2, 2, 3>(a, transA, transB, grid,
 // this kernel; the caller then uses qt_gemm_f32.
 // half_type: 0 fp16 parts x3, 1 bf16 parts x3, 3 = ONE bf16 product per term (reduced precision, BASELINE config 5's
 // 16-bit mode: operands rounded to bf16, fp32 accumulate); +16 forces the 128x128 tile, +32 forces the 256x256 tile (A/B testing).
+bool qt_gemm_sk_wants(int M, int N, int K, int batch);                                    // gemm_skinny.hip
+int qt_gemm_sk(void* stream, int half_type, int transA, int transB, int M, int N, int K, float alpha,
+               const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+               const float* bias, const float* add_src, long ld_add, int relu,
+               const float* mask_src, long ld_mask, float mask_scale,
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
+               int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax, float* c_amax);
+
 extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N, int K, float alpha,
                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                           const float* bias, const float* add_src, long ld_add, int relu,
@@ -527,7 +535,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     if (batch < 1) batch = 1;
     QT_CHECK_ARG(batch == 1 || (!bias && !add_src && !mask_src && !a_colsum), "qt_gemm_x3: batched launches take no bias/residual/mask/colsum");
     QT_CHECK_ARG(batch <= 65535, "qt_gemm_x3: batch too large");
-    const int force = half_type >> 4;
+    const int force = half_type >> 4;                               // 1 / 2: force the 128 / 256 tile; 4: force the skinny kernel; 8: never the skinny kernel
     half_type &= 15;
     QT_CHECK_ARG(half_type == 0 || half_type == 1 || half_type == 3, "qt_gemm_x3: half_type must be 0 (3x fp16), 1 (3x bf16) or 3 (1x bf16)");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_x3: drop_p=%f", drop_p);
@@ -541,6 +549,10 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         const long spanB = transB ? ((long)N * ldb + 32) : ((long)32 * ldb + N);
         if (spanA * 4 >= (1L << 32) || spanB * 4 >= (1L << 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "qt_gemm_x3: operand spans more than 4 GiB");
     }
+    // small problems (the per-sample layers, M = batch size): one 64x64 tile per workgroup, K split over its waves (gemm_skinny.hip)
+    if (!(force & 11) && ((force & 4) || qt_gemm_sk_wants(M, N, K, batch)))
+        return qt_gemm_sk(stream, half_type, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, add_src, ld_add, relu, mask_src, ld_mask,
+                          mask_scale, drop_p, drop_seed, accumulate, split_k, a_colsum, batch, a_bs, b_bs, c_bs, a_amax, b_amax, c_amax);
     // one problem: small ones belong to the exact-fp32 kernel's 64x64 tiles.  Many small problems in one launch (TSPM's
     // 60x60x512 score / gradient products, one per item) still fill the chip with one 128x128 tile each.
     if (batch == 1 ? ((long)M * N < 128L * 128L || M < 64 || N < 64) : (M < 16 || N < 16))
@@ -568,8 +580,8 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         const long rounds_small = (4 * tb + 511) / 512, rounds_big = (tb + 255) / 256;
         if (tb <= 1024 && 0.68 * (double)rounds_small < (double)rounds_big) big = false;
     }
-    if (force == 1) big = false;
-    if (force == 2) big = true;
+    if (force & 1) big = false;
+    if (force & 2) big = true;
     const int BT = big ? 256 : 128;
     const long slots = big ? 256 : 512;                             // resident workgroups
     const int tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;

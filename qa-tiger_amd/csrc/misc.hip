@@ -207,19 +207,43 @@ __global__ __launch_bounds__(256) void qt_adam_kernel(float* __restrict__ p, con
     }
 }
 
-// Device-side step count for a CAPTURED train step: step_dev[0] is incremented and the two bias corrections are written to
-// bc_dev[0..1] by a one-thread kernel; the update kernel reads them from memory instead of taking them as (frozen) arguments.
-static __global__ void qt_adam_prep_kernel(long long* step_dev, float* bc_dev, float b1, float b2) {
+// Device-side optimizer state for a CAPTURED train step.  Kernel arguments are frozen inside a HIP graph, so everything that changes from
+// step to step lives in memory: step_dev[0] (the step count) and hp_dev[0..7] = { 1 - b1^t, sqrt(1 - b2^t), lr, b1, b2, eps, weight_decay,
+// grad_scale }.  qt_adam_set_dev (launched OUTSIDE the graph, before a replay) writes the count and hp[2..7] from the host's values, so a
+// learning-rate scheduler or a loaded optimizer state reaches every replay; the captured qt_adam_step_dev increments the count, derives
+// the two bias corrections and updates the parameters reading all of it from memory.
+#define QT_HP_BC1 0
+#define QT_HP_BC2 1
+#define QT_HP_LR 2
+#define QT_HP_B1 3
+#define QT_HP_B2 4
+#define QT_HP_EPS 5
+#define QT_HP_WD 6
+#define QT_HP_GS 7
+static __global__ void qt_adam_set_kernel(long long* step_dev, float* hp, long long step, float lr, float b1, float b2, float eps, float wd, float gs) {
+    if (threadIdx.x == 0) {
+        *step_dev = step;
+        hp[QT_HP_LR] = lr; hp[QT_HP_B1] = b1; hp[QT_HP_B2] = b2; hp[QT_HP_EPS] = eps; hp[QT_HP_WD] = wd; hp[QT_HP_GS] = gs;
+    }
+}
+extern "C" int qt_adam_set_dev(void* stream, long long* step_dev, float* hp_dev, long long step, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float grad_scale) {
+    QT_CHECK_ARG(step_dev && hp_dev && step >= 0, "qt_adam_set_dev: bad arguments");
+    hipLaunchKernelGGL(qt_adam_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, hp_dev, step, lr, beta1, beta2, eps, weight_decay, grad_scale);
+    QT_CHECK_LAUNCH("qt_adam_set_dev");
+    return QT_OK;
+}
+static __global__ void qt_adam_prep_kernel(long long* step_dev, float* hp) {
     if (threadIdx.x == 0) {
         const long long t = ++(*step_dev);
-        bc_dev[0] = (float)(1.0 - pow((double)b1, (double)t));
-        bc_dev[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+        hp[QT_HP_BC1] = (float)(1.0 - pow((double)hp[QT_HP_B1], (double)t));
+        hp[QT_HP_BC2] = (float)sqrt(1.0 - pow((double)hp[QT_HP_B2], (double)t));
     }
 }
 __global__ __launch_bounds__(256) void qt_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                          float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                          const float* __restrict__ bc, float grad_scale, float wd) {
-    const float bc1 = bc[0], bc2_sqrt = bc[1];
+                                                          float* __restrict__ v, long n, const float* __restrict__ hp) {
+    const float bc1 = hp[QT_HP_BC1], bc2_sqrt = hp[QT_HP_BC2], lr = hp[QT_HP_LR], b1 = hp[QT_HP_B1], b2 = hp[QT_HP_B2], eps = hp[QT_HP_EPS],
+                wd = hp[QT_HP_WD], grad_scale = hp[QT_HP_GS];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gr = g[i] * grad_scale + wd * p[i];
         const float mm = b1 * m[i] + (1.f - b1) * gr, vv = b2 * v[i] + (1.f - b2) * gr * gr;
@@ -228,14 +252,13 @@ __global__ __launch_bounds__(256) void qt_adam_dev_kernel(float* __restrict__ p,
     }
 }
 extern "C" int qt_adam_step_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
-                                long long* step_dev, float* bc_dev, float lr, float beta1, float beta2, float eps, float grad_scale, float weight_decay) {
-    QT_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev && bc_dev, "qt_adam_step_dev: bad arguments");
+                                long long* step_dev, float* hp_dev) {
+    QT_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev && hp_dev, "qt_adam_step_dev: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(qt_adam_prep_kernel, dim3(1), dim3(64), 0, st, step_dev, bc_dev, beta1, beta2);
+    hipLaunchKernelGGL(qt_adam_prep_kernel, dim3(1), dim3(64), 0, st, step_dev, hp_dev);
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(qt_adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       bc_dev, grad_scale, weight_decay);
+    hipLaunchKernelGGL(qt_adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, hp_dev);
     QT_CHECK_LAUNCH("qt_adam_step_dev");
     return QT_OK;
 }

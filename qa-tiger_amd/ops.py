@@ -41,7 +41,8 @@ else:
 # split-in-the-consumer kernels (gemm_split.hip, with the same per-tensor scales applied inside the kernel).
 plane = _os.environ.get('QT_PLANE', '1') != '0'      # and precision['fwd'] == 'f16x3', checked per call: bench.py switches modes at run time
 weights_epoch = 0          # bumped whenever parameter memory is rewritten behind autograd's back (train.FusedAdam.step)
-_HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'bf16x1': 3, 'f16x3_t128': 16, 'bf16x3_t128': 17, 'f16x3_t256': 32, 'bf16x3_t256': 33}   # _tNNN: force a tile (A/B testing)
+_HALF_TYPE = {'f16x3': 0, 'bf16x3': 1, 'bf16x1': 3, 'f16x3_t128': 16, 'bf16x3_t128': 17, 'f16x3_t256': 32, 'bf16x3_t256': 33,
+              'f16x3_sk': 64, 'bf16x3_sk': 65, 'f16x3_nosk': 128, 'bf16x3_nosk': 129}   # _tNNN: force a tile (A/B testing)
 
 
 # --------------------------------------------------------------------------- #
@@ -259,7 +260,51 @@ class _AmaxPool:
         return rec
 
 
+    def zero_all(self) -> None:
+        """Zero both halves now (after a graph capture: the capture recorded the zeroing kernel without running it, and the half beyond
+        the captured range still holds warm-up values)."""
+        if self.buf is not None:
+            _lib.check(_lib.load().qt_zero_f32(_stream(), _ptr(self.buf), self.buf.numel()), 'qt_zero_f32')
+
+
 _amax_pool = _AmaxPool()
+
+# While a HIP graph is being captured (train.GraphedForward / GraphedTrainStep) nothing that is computed may come from, or go to, a
+# host-side cache: a cached weight image would freeze the capture-time model state into the graph, and an image "made" during the
+# capture holds no data until the first replay.  Operands made during a capture are shared within it through this dict (owned by the
+# object that owns the graph, which also keeps them alive) and never touch the caches on parameters / tensors.
+capture_keep: Optional[dict] = None
+
+
+def _capturing() -> bool:
+    return torch.cuda.is_current_stream_capturing()
+
+
+def _captured(key, make):
+    """`make()` once per capture and key (or every time when the capture is not one of ours)."""
+    if capture_keep is None:
+        return make()
+    hit = capture_keep.get(key)
+    if hit is None:
+        hit = capture_keep[key] = make()
+    return hit
+
+
+_salt_word: Optional[Tensor] = None
+
+
+def dropout_salt(device) -> Tensor:
+    """The per-process dropout salt word (include/qatiger.h qt_set_dropout_salt): ONE int64 device word, allocated on first use,
+    registered with the library and never freed or replaced, so the pointer the library keeps cannot dangle and every engine of the
+    process bumps the same word.  Zero until a captured train step bumps it; eager steps then add its (constant between bumps) value to
+    their seeds in forward and backward alike."""
+    global _salt_word
+    if _salt_word is None:
+        _salt_word = torch.zeros(1, dtype=torch.int64, device=device)
+    elif _salt_word.device != torch.device(device):
+        raise _lib.QTError(f'dropout salt lives on {_salt_word.device}; one process drives one GPU')
+    _lib.check(_lib.load().qt_set_dropout_salt(_ptr(_salt_word)), 'qt_set_dropout_salt')
+    return _salt_word
 
 
 def new_amax(device) -> Tensor:
@@ -465,6 +510,23 @@ grads_prezeroed = False     # train.GradSync.begin() zeroes the flat gradient bu
 direct_grads = False        # set by train.GradSync.begin() (device steps only), cleared by finish()
 grad_ready_cb = None        # callable(parameter): all rows of the parameter's gradient have been written in place
 _claimed_rows = {}          # id(parameter) -> [parameter, rows written in place so far, [(r0, r1), ...]]
+_fwd_use_rows = {}          # id(parameter) -> rows of it this step's FORWARD consumed through producers that may claim its gradient
+grad_write_cb = None        # callable(parameter): one producer has written (part of) the parameter's gradient in place (GradSync.trace)
+
+
+def _note_use(*params: Optional[Tensor]) -> None:
+    """Forward side of the in-place gradient protocol: count how many rows of each parameter this step's forward consumes.  A
+    parameter is reported complete from `_grad_written` only when the rows written in place equal the rows consumed — a weight used
+    twice (QstGrounding is called twice per forward, net.py:136-138; the second use cannot claim and its gradient arrives through
+    autograd's AccumulateGrad) is then completed by the post-accumulate hook, which runs after ALL uses, never by the first writer."""
+    if not direct_grads:
+        return
+    for t in params:
+        if t is None or not t.requires_grad:
+            continue
+        pr = _param_rows(t)
+        if pr is not None:
+            _fwd_use_rows[id(pr[0])] = _fwd_use_rows.get(id(pr[0]), 0) + pr[2]
 
 
 def _param_rows(t: Tensor):
@@ -529,7 +591,11 @@ def _grad_written(param: Tensor, view: Tensor):
     base, r0, rows = _param_rows(param)
     ent = _claimed_rows[id(base)]
     ent[1] += rows
-    if ent[1] >= (base.shape[0] if base.dim() > 0 else 1) and grad_ready_cb is not None:
+    if grad_write_cb is not None:
+        grad_write_cb(base)
+    # complete only if no other producer can still deliver: every forward use of the parameter has written in place (a use that could
+    # not claim hands its gradient to autograd, whose AccumulateGrad + post-accumulate hook then complete the parameter after all uses)
+    if ent[1] >= (base.shape[0] if base.dim() > 0 else 1) and _fwd_use_rows.get(id(base)) == ent[1] and grad_ready_cb is not None:
         grad_ready_cb(base)
     return None
 
@@ -575,6 +641,9 @@ def weight_image(weight: Tensor) -> Optional[SplitImage]:
                 flat.refresh_images()
         o = base._qt_flat_off
         img = SplitImage(flat.img[o:o + base.numel()].view(rows_b, cols), rows_b, cols, base._qt_amax_view)
+    elif _capturing():                               # rebuilt inside the graph: replays follow the weights
+        with torch.no_grad():
+            img = _captured(('wimg', id(base)), lambda: split_image(base.detach(), scaled=True, keep=True))
     else:
         key = (base._version, weights_epoch, base.data_ptr())
         cached = getattr(base, '_qt_wimg', None)
@@ -597,13 +666,17 @@ def weight_image_fp8(weight: Tensor) -> Optional[SplitImage]:
     rows_b, cols = base.shape
     if cols % 128 or weight.shape[1] != cols:
         return None
-    key = (base._version, weights_epoch, base.data_ptr())
-    cached = getattr(base, '_qt_wimg8', None)
-    if cached is None or cached[0] != key:
+    if _capturing():
         with torch.no_grad():
-            cached = (key, quant_fp8(base.detach(), keep=True))
-        base._qt_wimg8 = cached
-    img = cached[1]
+            img = _captured(('wimg8', id(base)), lambda: quant_fp8(base.detach(), keep=True))
+    else:
+        key = (base._version, weights_epoch, base.data_ptr())
+        cached = getattr(base, '_qt_wimg8', None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, quant_fp8(base.detach(), keep=True))
+            base._qt_wimg8 = cached
+        img = cached[1]
     r0 = (weight.storage_offset() - base.storage_offset()) // cols
     if weight.shape[0] == rows_b and r0 == 0:
         return img
@@ -611,9 +684,10 @@ def weight_image_fp8(weight: Tensor) -> Optional[SplitImage]:
 
 
 def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
+    if _capturing():                               # in the graph, shared within the capture only
+        return _captured(('ximg8', id(x), x._version, tuple(x2.shape)), lambda: (quant_fp8(x2.detach(), keep=True), x))[0]
     cached = getattr(x, '_qt_img8', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape \
-            and not torch.cuda.is_current_stream_capturing():
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
         return cached[1]
     img = quant_fp8(x2.detach(), keep=True)        # cached on the tensor object
     x._qt_img8 = ((x._version, x.data_ptr()), img)
@@ -623,10 +697,16 @@ def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
 def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     """Split image of an activation (x2 = the [rows, k_in] view of x), made once per tensor object: the layers that read the
     same tensor (the three in-projections of AVQCrossAttn, ...) and the dW GEMM of the backward share it."""
+    if _capturing():
+        # the split must be IN the graph (a cached image would freeze the warm-up batch into it) and is shared only within the capture
+        # (the tuple keeps x alive, so id(x) stays unique for the capture)
+        def make():
+            with torch.no_grad():
+                am = act_amax(x, x2)
+                return split_image(x2.detach(), scaled=am is not None, amax=am), x
+        return _captured(('ximg', id(x), x._version, tuple(x2.shape)), make)[0]
     cached = getattr(x, '_qt_img', None)
-    # (while a HIP graph is being captured the split must be IN the graph: a cached image would freeze the warm-up batch into it)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape \
-            and not torch.cuda.is_current_stream_capturing():
+    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
         return cached[1]
     with torch.no_grad():
         # robust-range mode: activations beyond fp16's range are scaled by their max|x| first (act_amax); by default the parts are unscaled
@@ -653,11 +733,15 @@ def weight_amax(weight: Tensor) -> Optional[Tensor]:
         if flat.amax_epoch != weights_epoch or getattr(base, '_qt_amax_ver', -1) != base._version:
             flat.refresh_amax()
         return view
+    def measure():
+        with torch.no_grad():
+            return amax_of(base.detach().reshape(-1, base.shape[-1]) if base.dim() > 1 else base.detach().reshape(1, -1), keep=True)
+    if _capturing():
+        return _captured(('wamax', id(base)), measure)
     key = (base._version, weights_epoch, base.data_ptr())
     cached = getattr(base, '_qt_wamax', None)
     if cached is None or cached[0] != key:
-        with torch.no_grad():
-            cached = (key, amax_of(base.detach().reshape(-1, base.shape[-1]) if base.dim() > 1 else base.detach().reshape(1, -1), keep=True))
+        cached = (key, measure())
         base._qt_wamax = cached
     return cached[1]
 
@@ -666,8 +750,10 @@ def act_amax(x: Tensor, x2: Tensor) -> Optional[Tensor]:
     """max|x| of a Linear input, only in the robust-range mode (activations beyond fp16's range, e.g. |x| ~ 1e5)."""
     if not robust_range or precision['fwd'] != 'f16x3':
         return None
+    if _capturing():
+        return _captured(('xamax', id(x), x._version), lambda: (amax_of(x2.detach(), keep=True), x))[0]
     cached = getattr(x, '_qt_xamax', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and not torch.cuda.is_current_stream_capturing():
+    if cached is not None and cached[0] == (x._version, x.data_ptr()):
         return cached[1]
     am = amax_of(x2.detach(), keep=True)           # read again by the backward's dW GEMM: not a pooled slot
     x._qt_xamax = ((x._version, x.data_ptr()), am)
@@ -694,6 +780,7 @@ class LinearFn(torch.autograd.Function):
         x2 = as2d(x)
         y = None
         ximg = wimg = None
+        _note_use(weight, bias)
         if precision['fwd'] == 'fp8':
             # BASELINE configs[4]: projection GEMMs on fp8 MFMA (forward only; the router / Gaussian / softmax / LayerNorm
             # statistics and every small GEMM stay in fp32 — SURVEY.md Appendix E)
@@ -937,6 +1024,7 @@ class HeadExpandFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q: Tensor, w: Tensor, H: int):
         q2, w2 = as2d(q), as2d(w)
+        _note_use(w)
         M, E = q2.shape
         D, dh = w2.shape[1], E // H
         u = torch.empty((M, H * D), device=q2.device, dtype=torch.float32)
@@ -989,6 +1077,7 @@ class HeadContractFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, c: Tensor, w: Tensor, H: int):
         c2, w2 = as2d(c), as2d(w)
+        _note_use(w)
         M = c2.shape[0]
         D = w2.shape[1]
         dh = w2.shape[0] // H
@@ -1118,6 +1207,7 @@ class AddLayerNormFn(torch.autograd.Function):
         n = len(xs)
         x2 = [as2d(x) for x in xs]
         _dev(gamma, beta, *x2)
+        _note_use(gamma, beta)
         rows, D = x2[0].shape
         for x in x2:
             assert x.shape == (rows, D)
@@ -1241,6 +1331,7 @@ class StackParamsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode: str, *params: Tensor):
         ctx.mode, ctx.plist = mode, params
+        _note_use(*params)
         if mode == 'rows':
             return torch.cat(params, dim=0)
         if mode == 'cols':

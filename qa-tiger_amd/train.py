@@ -169,6 +169,11 @@ class GradSync:
             if self._pending[b] == 0 and not self.defer:
                 self._fire(b)
 
+    def _written(self, p: Tensor):
+        """ops.grad_write_cb (tracing only): a producer has accumulated (part of) p's gradient in place."""
+        if getattr(p, '_qt_flat', None) is self.flat:
+            self.trace.append(('write', p._qt_idx))
+
     def _claimed_ready(self, p: Tensor):
         """ops.grad_ready_cb: every row of p's gradient has been accumulated in place by its producers (no autograd hand-over)."""
         if getattr(p, '_qt_flat', None) is self.flat or p._qt_gv is self.flat.grad_views[p._qt_idx]:
@@ -188,6 +193,7 @@ class GradSync:
         self.flat.check()
         ops.grad_claims.clear()
         ops._claimed_rows.clear()
+        ops._fwd_use_rows.clear()
         if self.flat.grad.is_cuda:                # one launch; claimed dW / db producers accumulate into it (ops.grads_prezeroed)
             ops._lib.check(ops._lib.load().qt_zero_f32(ops._stream(), ops._ptr(self.flat.grad), self.flat.grad.numel()), 'qt_zero_f32')
             ops.grads_prezeroed = True                   # first producer of a parameter's gradient this step may write in place
@@ -197,6 +203,7 @@ class GradSync:
                 p.grad = gv
             ops.direct_grads = True
             ops.grad_ready_cb = self._claimed_ready
+            ops.grad_write_cb = self._written if self.trace is not None else None
         else:
             for p in self.flat.params:
                 p.grad = None
@@ -222,6 +229,7 @@ class GradSync:
         ops.grads_prezeroed = False
         ops.direct_grads = False
         ops.grad_ready_cb = None
+        ops.grad_write_cb = None
         for b, fired in enumerate(self._fired):
             if not fired:
                 self._fire(b)
@@ -285,16 +293,27 @@ class FusedAdam(torch.optim.Optimizer):
         ops.weights_epoch += 1                          # parameter memory rewritten by a raw kernel: cached weight images are stale
         return loss
 
-    @torch.no_grad()
-    def step_dev(self, step_dev: Tensor, bc_dev: Tensor, grad_scale: float = 1.0):
-        """The same update with the step count in device memory (`step_dev` int64[1] is incremented by the kernel): the form a
-        captured train step needs, whose kernel arguments are frozen (include/qatiger.h qt_adam_step_dev)."""
+    def sync_dev(self, step_dev: Tensor, hp_dev: Tensor, grad_scale: float = 1.0) -> None:
+        """Write the host's view of the optimizer — step count, lr, betas, eps, weight_decay of the param group as they are NOW — into
+        the device words a captured update reads (include/qatiger.h qt_adam_set_dev).  GraphedTrainStep calls this before every replay,
+        so `StepLR.step()`, `ReduceLROnPlateau`, a hand-set `param_groups[0]['lr']` or `load_state_dict` after the capture reach the
+        replayed kernel exactly as they reach the eager `step()` (reference trainutils.py:147-182)."""
+        if len(self.param_groups) != 1:
+            raise ValueError('FusedAdam updates one flat buffer: exactly one param group')
         g = self.param_groups[0]
+        rc = ops._lib.load().qt_adam_set_dev(ops._stream(), ops._ptr(step_dev), ops._ptr(hp_dev), int(self.step_count), float(g['lr']),
+                                            float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
+                                            float(grad_scale))
+        ops._lib.check(rc, 'qt_adam_set_dev')
+
+    @torch.no_grad()
+    def step_dev(self, step_dev: Tensor, hp_dev: Tensor):
+        """The same update with the step count AND the hyper-parameters in device memory (`sync_dev` wrote them; the kernel increments
+        `step_dev` int64[1] and derives the bias corrections): the form a captured train step needs, whose kernel arguments are
+        frozen (include/qatiger.h qt_adam_step_dev)."""
         self.step_count += 1
         rc = ops._lib.load().qt_adam_step_dev(ops._stream(), ops._ptr(self.flat.flat), ops._ptr(self.flat.grad), ops._ptr(self.exp_avg),
-                                             ops._ptr(self.exp_avg_sq), self.flat.flat.numel(), ops._ptr(step_dev), ops._ptr(bc_dev),
-                                             float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(grad_scale),
-                                             float(g['weight_decay']))
+                                             ops._ptr(self.exp_avg_sq), self.flat.flat.numel(), ops._ptr(step_dev), ops._ptr(hp_dev))
         ops._lib.check(rc, 'qt_adam_step_dev')
         ops.weights_epoch += 1
 
@@ -372,8 +391,10 @@ class GraphedTrainStep:
     What makes the step capturable (include/qatiger.h): no runtime memset/memcpy nodes from the library (every zeroing is a kernel), no
     allocation or synchronisation inside an entry point, dropout seeds salted from a DEVICE word that a one-thread kernel bumps inside the
     captured step (qt_set_dropout_salt / qt_bump_dropout_salt: fresh masks at every replay, forward and backward of one step still
-    agree), the Adam step count and bias corrections in device memory (qt_adam_step_dev), max|x| records from a pool whose zeroing
-    kernel is part of the capture.  Shapes and the learning-rate hyper-parameters are frozen at capture.
+    agree), the Adam step count, bias corrections AND hyper-parameters in device memory (qt_adam_set_dev / qt_adam_step_dev: the param
+    group's lr / betas / eps / weight_decay and the host's step count are written before every replay, so schedulers and
+    `load_state_dict` act on replays as they do on eager steps), max|x| records from a pool whose zeroing kernel is part of the
+    capture, and the weights' max|w| records / split images refreshed INSIDE the captured step.  Only shapes are frozen at capture.
 
     world > 1: forward + backward are captured, the gradient all-reduce (RCCL) and the optimizer run eagerly after the replay
     (one replay + one collective per bucket + two launches per step)."""
@@ -387,31 +408,42 @@ class GraphedTrainStep:
             raise ops._lib.QTError('GraphedTrainStep needs an MI355X (cuda) device')
         self.distributed = engine.sync.world > 1 or engine.sync.force_collective
         self.lib = ops._lib.load()
-        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
-        ops._lib.check(self.lib.qt_set_dropout_salt(ops._ptr(self.salt)), 'qt_set_dropout_salt')     # library-global: one engine per process
+        self.salt = ops.dropout_salt(dev)               # ONE word per process, owned by ops for the process lifetime (never freed or re-pointed)
         self.step_dev = torch.tensor([engine.optim.step_count], dtype=torch.int64, device=dev)
-        self.bc = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.hp = torch.zeros(8, dtype=torch.float32, device=dev)
         self.static_in = {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in example.items()}
         engine.sync.defer = True
-        steps_before = engine.optim.step_count
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                     # lazy initialisation and allocator warm-up outside the capture
+                self._sync_optim()
                 self._captured_part()
                 self._eager_part()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        steps_before = engine.optim.step_count
         ops._amax_pool.cur = 0                          # the pool's zeroing kernel must be inside the capture
         engine.flat.amax_epoch = engine.flat.img_epoch = None   # ... and so must the refresh of the weights' max|w| records and images
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_loss = self._captured_part()
-        engine.optim.step_count = steps_before + warmup      # the capture pass records work, it does not run it
-        if self.distributed:                            # the captured begin() left its host flags set; finish() (eager part) clears them per step
-            ops.grads_prezeroed = False
-            ops.direct_grads = False
-            ops.grad_ready_cb = None
+        self._keep: dict = {}                           # operands made during the capture (weight images of parameters outside FlatParams, ...)
+        ops.capture_keep = self._keep
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._captured_part()
+        finally:
+            ops.capture_keep = None
+        engine.optim.step_count = steps_before          # the capture pass records work, it does not run it
+        # ... so whatever the capture "refreshed" holds no data yet: host-side caches must not claim otherwise (an eager step between
+        # capture and first replay re-measures), and the record pool's other half still carries warm-up values
+        engine.flat.amax_epoch = engine.flat.img_epoch = None
+        ops._amax_pool.zero_all()
+        ops.grads_prezeroed = False                     # the captured begin() left its host flags set; each replay / eager step sets its own
+        ops.direct_grads = False
+        ops.grad_ready_cb = None
+
+    def _sync_optim(self) -> None:
+        self.eng.optim.sync_dev(self.step_dev, self.hp, grad_scale=1.0 / self.eng.sync.world if self.distributed else 1.0)
 
     def _captured_part(self) -> Tensor:
         eng = self.eng
@@ -422,19 +454,21 @@ class GraphedTrainStep:
         loss.backward()
         if not self.distributed:
             eng.sync.finish()
-            eng.optim.step_dev(self.step_dev, self.bc, grad_scale=1.0)
+            eng.optim.step_dev(self.step_dev, self.hp)
         return loss.detach()
 
     def _eager_part(self) -> None:
         if self.distributed:
             eng = self.eng
             eng.sync.finish()                           # fires every bucket's all-reduce now, waits
-            eng.optim.step_dev(self.step_dev, self.bc, grad_scale=1.0 / eng.sync.world)
+            eng.optim.step_dev(self.step_dev, self.hp)
 
     def __call__(self, batch: Dict[str, Tensor]) -> Tensor:
         for k, v in self.static_in.items():
             if isinstance(v, Tensor) and batch[k] is not v:
                 v.copy_(batch[k], non_blocking=True)
+        self.eng.flat.check()
+        self._sync_optim()                              # host step count + current lr / betas / eps / weight_decay -> device (outside the graph)
         self.eng.sync.reset_host_state()                # (begin() ran at capture time only)
         self.graph.replay()
         if self.distributed:
@@ -443,6 +477,7 @@ class GraphedTrainStep:
         else:
             self.eng.optim.step_count += 1
             ops.weights_epoch += 1                      # parameter memory changed: host-side caches (weight scales) are stale for eager callers
+        self.eng.optim._opt_called = True               # (torch's lr schedulers warn when they see no optimizer.step() before their own)
         return self.static_loss
 
 
@@ -470,13 +505,28 @@ class GraphedForward:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                     # lazy initialisation (library load, kernel attributes, weight scales) outside the capture
+            for _ in range(warmup):                     # lazy initialisation (library load, kernel attributes) outside the capture
                 model(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         ops._amax_pool.cur = 0                          # (any pooled max|x| record the forward takes is zeroed inside the capture)
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.static_out = model(self.static_in)
+        # The weights' max|w| records and split images are REBUILT inside the capture, so a replay after an optimizer step, a
+        # `load_state_dict` or any other in-place change of the parameters computes from the weights as they are then, like the eager
+        # forward (cached images from the warm-up would freeze the model state of the capture into the graph).  FlatParams buffers
+        # are persistent; images of other parameters are kept alive here for as long as the graph is.
+        flats = {id(f): f for f in (getattr(p, '_qt_flat', None) for p in model.parameters()) if f is not None}
+        for f in flats.values():
+            f.amax_epoch = f.img_epoch = None
+        self._keep: dict = {}
+        ops.capture_keep = self._keep
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.static_out = model(self.static_in)
+        finally:
+            ops.capture_keep = None
+        for f in flats.values():                        # the capture recorded the refresh, it did not run it
+            f.amax_epoch = f.img_epoch = None
+        ops._amax_pool.zero_all()
 
     def __call__(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         for k, v in self.static_in.items():

@@ -76,6 +76,31 @@ def main(rank: int, world: int, port: int) -> int:
     rep['buckets_fired_during_backward'] = fired_before_finish
     ok = ok and fired_before_finish >= len(eng.sync.buckets) - 1
 
+    # no bucket may go on the wire before the LAST contribution to any of its parameters has been launched: a weight used twice per
+    # forward (QstGrounding, net.py:136-138) gets one contribution written in place by its first producer and the other through
+    # autograd's AccumulateGrad — checked with every parameter a bucket of its own, where nothing else can hide an early all-reduce
+    # ('write': a producer accumulated in place; 'deliver': autograd handed AccumulateGrad a defined gradient, seen by a tensor hook)
+    one = engine(1, with_group=True)
+    one.sync.trace = tr = []
+    for i, q in enumerate(one.flat.params):
+        q.register_hook(lambda g, i=i: tr.append(('deliver', i)) if g is not None else None)    # (tensor hooks also see the undefined gradients in-place producers return)
+    one.forward_backward(shard)
+    torch.cuda.synchronize()
+    one.sync.trace = None
+    fire_at = {e[1]: i for i, e in enumerate(tr) if e[0] == 'fire'}
+    late = [(e[0], e[1]) for i, e in enumerate(tr) if e[0] in ('write', 'deliver') and fire_at[one.sync.bucket_of[e[1]]] < i]
+    shared = sum(1 for i in range(len(one.flat.params))
+                 if sum(1 for e in tr if e[0] in ('write', 'deliver') and e[1] == i) > 1)
+    rep['per_param_buckets'], rep['contributions_after_fire'], rep['params_with_several_contributions'] = len(one.sync.buckets), len(late), shared
+    if late:                                                              # name the offenders
+        names = [n for n, q in one.model.named_parameters() if q.requires_grad]
+        rep['late'] = [(names[i], [(j, e[0]) for j, e in enumerate(tr) if len(e) > 1 and e[1] == i and e[0] != 'fire'], fire_at[one.sync.bucket_of[i]])
+                       for i in sorted({e[1] for e in late})[:6]]
+    ok = ok and len(one.sync.buckets) == len(one.flat.params) and not late and shared >= 8
+    err1 = float((one.flat.grad - g_local).abs().max() / g_local.abs().max()) if world == 1 else 0.0
+    rep['per_param_bucket_grad_rel_err'] = err1
+    ok = ok and err1 < 1e-5
+
     # SUM over ranks of the local gradients
     ref = g_local.clone()
     dist.all_reduce(ref, op=dist.ReduceOp.SUM)

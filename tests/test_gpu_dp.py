@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bucket_bytes):
     try:
         sys.path.insert(0, REPO)
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
             ref = g if ref is None else [a + b for a, b in zip(ref, g)]
 
         model = fresh()
-        eng = qt.DataParallelStep(model, lr=1e-3, betas=(0.95, 0.999), bucket_bytes=64 << 10)   # many buckets
+        eng = qt.DataParallelStep(model, lr=1e-3, betas=(0.95, 0.999), bucket_bytes=bucket_bytes)   # many buckets
         assert eng.sync.world == world and len(eng.sync.buckets) > 3
         eng.forward_backward(shards[rank])
         torch.cuda.synchronize()
@@ -78,11 +78,15 @@ def _worker(rank, world, port, q):
         q.put((rank, repr(e) + traceback.format_exc(), False, False))
 
 
-def test_two_rank_step_on_hip_kernels():
+@pytest.mark.parametrize('bucket_bytes', [64 << 10, 1])
+def test_two_rank_step_on_hip_kernels(bucket_bytes):
+    """bucket_bytes = 1: every parameter is a bucket of its own, so a parameter reported complete by its first in-place producer while a
+    second use (QstGrounding's shared weights, net.py:136-138) has still to deliver would be all-reduced early and lose or double a
+    contribution — nothing else in the bucket can hide it."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bucket_bytes)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]

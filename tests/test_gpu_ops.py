@@ -62,6 +62,78 @@ def test_gemm_split_precision(ops, mode, tol, M, N, K, ta, tb):
     assert rel(out, (ref + bias.double()).clamp_min(0)) < tol
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 768, 768), (32, 768, 768), (768, 768, 32), (129, 130, 36), (300, 200, 100), (64, 42, 768), (17, 33, 8),
+                                   (512, 768, 3072), (1000, 384, 4100)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_skinny_kernel(ops, M, N, K, ta, tb):
+    """gemm_skinny.hip (forced with the `_sk` modes; `_nosk` = the tiled kernels of gemm_split.hip): one 64x64 tile per workgroup, K split
+    over its four waves, partial tiles summed in LDS in a fixed order.  Same arithmetic and epilogue contract as qt_gemm_x3: fp32-level
+    products, ragged M / N / K, every epilogue, per-tensor operand scales, the fused bias gradient, max|C| — and bit-identical results from
+    run to run (no atomics unless a grid-level K split is asked for)."""
+    a = rnd(*((K, M) if ta else (M, K)), seed=1)
+    b = rnd(*((N, K) if tb else (K, N)), seed=2, scale=0.05)
+    ad, bd = (a.double().t() if ta else a.double()), (b.double().t() if tb else b.double())
+    ref = ad @ bd
+    kw = dict(trans_a=ta, trans_b=tb)
+    out = ops.gemm(a, b, mode='f16x3_sk', **kw)
+    assert rel(out, ref) < 2e-6
+    assert torch.equal(out, ops.gemm(a, b, mode='f16x3_sk', **kw))                      # deterministic
+    assert rel(ops.gemm(a, b, mode='bf16x3_sk', **kw), ref) < 6e-5
+    for split in (2, 5):                                                                 # grid-level K split (atomics)
+        assert rel(ops.gemm(a, b, mode='f16x3_sk', split_k=split, **kw), ref) < 2e-6
+    bias, add, msk, c0 = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5), rnd(M, N, seed=6)
+    assert rel(ops.gemm(a, b, mode='f16x3_sk', bias=bias, add=add, relu=True, **kw), (ref + bias.double() + add.double()).clamp_min(0)) < 2e-6
+    assert rel(ops.gemm(a, b, mode='f16x3_sk', mask_src=msk, mask_scale=1.25, **kw), ref * (msk > 0) * 1.25) < 2e-6
+    c = c0.clone()
+    ops.gemm(a, b, mode='f16x3_sk', out=c, accumulate=True, alpha=0.5, bias=bias, **kw)
+    assert rel(c, c0.double() + 0.5 * ref + bias.double()) < 2e-6
+    c = c0.clone()
+    ops.gemm(a, b, mode='f16x3_sk', out=c, accumulate=True, split_k=3, **kw)
+    assert rel(c, c0.double() + ref) < 2e-6
+    # dropout: the same mask as the tiled kernel draws for the same (seed, element index)
+    d_sk = ops.gemm(a, b, mode='f16x3_sk', relu=True, drop_p=0.1, seed=99, **kw)
+    d_t = ops.gemm(a, b, mode='f16x3_nosk', relu=True, drop_p=0.1, seed=99, **kw)
+    big = ref.abs() > 1e-3 * ref.abs().max()                                            # (away from the ReLU threshold)
+    assert torch.equal((d_sk != 0)[big.to(DEV)], (d_t != 0)[big.to(DEV)]) and rel(d_sk, d_t) < 4e-6
+    # operand scales: gradients of 1e-9 against weights of 1e-4 keep fp32-level products
+    a9, b4 = a * 1e-9, b * 2e-3
+    am, bm = ops.amax_of(a9, keep=True), ops.amax_of(b4, keep=True)
+    cam = torch.zeros(ops.AMAX_SLOTS, device=DEV)
+    out = ops.gemm(a9, b4, mode='f16x3_sk', a_amax=am, b_amax=bm, c_amax=cam, **kw)
+    assert rel(out, ref * 2e-12) < 2e-6
+    assert float(cam.max()) == float(out.abs().max())
+    if ta:                                                                              # fused bias gradient (column sums of the K-slow A)
+        db = torch.full((M,), 7.0, device=DEV)
+        ops.gemm(a, b, mode='f16x3_sk', a_colsum=db, **kw)
+        assert rel(db, a.double().sum(0)) < 1e-5
+        db0 = rnd(M, seed=8)
+        db, c = db0.clone(), c0.clone()
+        ops.gemm(a, b, mode='f16x3_sk', a_colsum=db, out=c, accumulate=True, **kw)
+        assert rel(db, db0.double() + a.double().sum(0)) < 1e-5 and rel(c, c0.double() + ref) < 2e-6
+
+
+def test_gemm_skinny_batched_and_views(ops):
+    """Head-batched problems (strides between problems) and operands / outputs that are column blocks of wider tensors."""
+    nb, M, dh, D = 8, 200, 96, 768
+    q, w = rnd(M, nb * dh, seed=1), rnd(nb * dh, D, seed=2, scale=0.05)
+    u = torch.zeros(M, nb * D, device=DEV)
+    ops.gemm(q[:, :dh], w[:dh], trans_b=False, out=u[:, :D], batch=(nb, dh, dh * D, D), mode='f16x3_sk')     # u_h = q_h W_h
+    for hh in range(nb):
+        assert rel(u[:, hh * D:(hh + 1) * D], q[:, hh * dh:(hh + 1) * dh].double() @ w[hh * dh:(hh + 1) * dh].double()) < 2e-6
+    dq = torch.zeros(M, nb * dh, device=DEV)
+    ops.gemm(u[:, :D], w[:dh], trans_b=True, out=dq[:, :dh], batch=(nb, D, dh * D, dh), mode='f16x3_sk')     # dq_h = u_h W_h^T
+    for hh in range(nb):
+        assert rel(dq[:, hh * dh:(hh + 1) * dh], u[:, hh * D:(hh + 1) * D].double() @ w[hh * dh:(hh + 1) * dh].double().t()) < 2e-6
+    dw = torch.zeros(nb * dh, D, device=DEV)
+    ops.gemm(q[:, :dh], u[:, :D], trans_a=True, trans_b=False, out=dw[:dh], batch=(nb, dh, D, dh * D), mode='f16x3_sk')
+    for hh in range(nb):
+        assert rel(dw[hh * dh:(hh + 1) * dh], q[:, hh * dh:(hh + 1) * dh].double().t() @ u[:, hh * D:(hh + 1) * D].double()) < 2e-6
+    wide = torch.zeros(M, D + 50, device=DEV)
+    ops.gemm(q, w, trans_b=False, out=wide[:, 10:10 + D], mode='f16x3_sk')              # unaligned output columns
+    assert rel(wide[:, 10:10 + D], q.double() @ w.double()) < 2e-6
+    assert float(wide[:, :10].abs().max()) == 0 and float(wide[:, 10 + D:].abs().max()) == 0
+
+
 @pytest.mark.parametrize('M,N,K', [(768, 768, 30720), (2304, 512, 70000), (130, 200, 1000), (384, 768, 960)])
 def test_gemm_fused_bias_gradient(ops, M, N, K):
     """a_colsum: the column sums of the K-slow A operand (= bias gradient) computed inside the dW GEMM."""
