@@ -70,14 +70,14 @@ def _build_locked(srcs, verbose: bool, force: bool = False) -> str:
     flags = FLAGS
     objdir = os.path.join(CSRC, '_obj')
     os.makedirs(objdir, exist_ok=True)
-    # one object per translation unit, compiled in parallel; gemm_split.hip is built in parts (see its tail)
+    # one object per translation unit, compiled in parallel; gemm_split.hip and gemm_plane.hip are built in parts (see their tails)
     jobs = []
     for src in srcs:
         base = os.path.splitext(os.path.basename(src))[0]
-        parts = range(7) if base == 'gemm_split' else [None]
+        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else ((range(6), 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
         for part in parts:
             obj = os.path.join(objdir, base + ('' if part is None else f'_p{part}') + '.o')
-            jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-DQT_X3_PART={part}']), obj))
+            jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-D{macro}={part}']), obj))
 
     import hashlib
     with open(os.path.join(CSRC, 'qt_common.h'), 'rb') as f:
