@@ -178,6 +178,14 @@ int qt_adam_set_dev(void* stream, long long* step_dev, float* hp_dev, long long 
 int qt_adam_step_dev(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                      long long* step_dev, float* hp_dev);
 
+/* Value-bias term of an attention whose value projection is applied AFTER the attention-weighted sum (qt_xattn_fwd):
+ *   out[m, e] = o[m, e] + asum[m, e / (E/H)] * b_v[e]      (asum = qt_xattn_fwd's per-head sum of the dropped probabilities)
+ * replaces the `+ b_v` of nn.MultiheadAttention's value in-projection (modules.py:562, 698).  Backward: d o = d out;
+ * dasum[m, h] = sum_{e in head h} dout[m, e] b_v[e];  dbv[e] (+)= sum_m dout[m, e] asum[m, head(e)]  (dbv_accumulate: add to what dbv holds). */
+int qt_headbias_fwd(void* stream, const float* o, long ldo, const float* asum, const float* bv, long rows, int E, int H, float* out, long ldout);
+int qt_headbias_bwd(void* stream, const float* dout, long ld, const float* asum, const float* bv, long rows, int E, int H,
+                    float* dasum, float* dbv, int dbv_accumulate);
+
 /* ---- pre-split operands (csrc/gemm_plane.hip): the same Linear / projection GEMMs and their backward, on operands whose
  * fp32 -> (hi, lo) fp16 split was done ONCE by a producer pass instead of inside every tile of the GEMM. ---- */
 

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
 SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_skinny.hip', 'gemm_plane.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
-ABI_VERSION = 205          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
+ABI_VERSION = 206          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
 FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
@@ -140,6 +140,8 @@ SIGNATURES = {
     'qt_set_dropout_salt': [_p],
     'qt_bump_dropout_salt': [_p, _p, _u64],
     'qt_adam_step_dev': [_p, _p, _p, _p, _p, _l, _p, _p],
+    'qt_headbias_fwd': [_p, _p, _l, _p, _p, _l, _i, _i, _p, _l],
+    'qt_headbias_bwd': [_p, _p, _l, _p, _p, _l, _i, _i, _p, _p, _i],
     'qt_adam_set_dev': [_p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _f],
     'qt_amax_f32': [_p, _p, _l, _l, _i, _p, _i],
     'qt_amax_segments': [_p, _p, _p, _p, _i, _p],

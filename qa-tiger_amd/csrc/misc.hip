@@ -279,6 +279,89 @@ extern "C" int qt_adam_step(void* stream, float* param, const float* grad, float
     return QT_OK;
 }
 
+// ---- value-bias term of a folded attention (ops.folded_attention; reference nn.MultiheadAttention in-projection bias b_v) ------------
+// With W_v applied AFTER the attention-weighted sum, the bias contributes  out[m, e] = o[m, e] + asum[m, head(e)] * b_v[e]  where
+// asum[m, h] is the sum of head h's (dropped) attention probabilities of query row m (1 without dropout).  Forward: one elementwise pass;
+// backward: d asum[m, h] = sum_{e in head h} dOut[m, e] b_v[e]  and  d b_v[e] += sum_m dOut[m, e] asum[m, head(e)]  (d o = dOut itself).
+// (Round 2 did this as a K = H GEMM on a masked [E, H] weight built with ATen ops: three tiny-K GEMM launches and ~10 glue launches.)
+__global__ __launch_bounds__(256) void qt_headbias_fwd_kernel(const float* __restrict__ o, long ldo, const float* __restrict__ asum, const float* __restrict__ bv,
+                                                              long rows, int E, int dh, int H, float* __restrict__ out, long ldout) {
+    const long n4 = rows * (E >> 2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long m = i / (E >> 2); const int e = (int)(i - m * (E >> 2)) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(o + m * ldo + e);
+        const float4 b = *reinterpret_cast<const float4*>(bv + e);
+        const float a = asum[m * H + e / dh];                                    // dh % 4 == 0: the four columns share a head
+        *reinterpret_cast<float4*>(out + m * ldout + e) = make_float4(fmaf(a, b.x, x.x), fmaf(a, b.y, x.y), fmaf(a, b.z, x.z), fmaf(a, b.w, x.w));
+    }
+}
+extern "C" int qt_headbias_fwd(void* stream, const float* o, long ldo, const float* asum, const float* bv, long rows, int E, int H,
+                               float* out, long ldout) {
+    QT_CHECK_ARG(o && asum && bv && out && rows > 0 && E > 0 && H > 0 && E % H == 0 && (E / H) % 4 == 0 && ldo % 4 == 0 && ldout % 4 == 0,
+                 "qt_headbias_fwd: bad arguments");
+    QT_CHECK_ARG(qt_aligned16(o) && qt_aligned16(bv) && qt_aligned16(out), "qt_headbias_fwd: 16-byte alignment");
+    long blocks = (rows * (E >> 2) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(qt_headbias_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, o, ldo, asum, bv, rows, E, E / H, H, out, ldout);
+    QT_CHECK_LAUNCH("qt_headbias_fwd");
+    return QT_OK;
+}
+// one workgroup = a chunk of rows; thread t owns columns t, t + 256, ... (coalesced rows), keeps its share of d b_v in registers over the
+// chunk and folds each row's per-head sums in LDS; one atomic per column per workgroup into d b_v (zeroed by the caller or a claimed slice
+// of the pre-zeroed flat gradient buffer)
+#define QT_HB_ROWS 32
+#define QT_HB_MAXC 8            // columns per thread: E <= 2048
+__global__ __launch_bounds__(256) void qt_headbias_bwd_kernel(const float* __restrict__ dout, long ld, const float* __restrict__ asum, const float* __restrict__ bv,
+                                                              long rows, int E, int dh, int H, float* __restrict__ dasum, float* __restrict__ dbv) {
+    __shared__ float hs[QT_HB_ROWS][33];                                        // per-row, per-head partial sums (H <= 32)
+    const long r0 = (long)blockIdx.x * QT_HB_ROWS;
+    const int nr = (int)min((long)QT_HB_ROWS, rows - r0);
+    for (int i = threadIdx.x; i < QT_HB_ROWS * 33; i += 256) (&hs[0][0])[i] = 0.f;
+    __syncthreads();
+    float acc[QT_HB_MAXC], bcol[QT_HB_MAXC];
+    int hcol[QT_HB_MAXC];
+#pragma unroll
+    for (int c = 0; c < QT_HB_MAXC; ++c) {
+        const int e = threadIdx.x + c * 256;
+        acc[c] = 0.f; bcol[c] = e < E ? bv[e] : 0.f; hcol[c] = e < E ? e / dh : 0;
+    }
+    for (int r = 0; r < nr; ++r) {
+        const float* drow = dout + (r0 + r) * ld;
+        const float* arow = asum + (r0 + r) * H;
+#pragma unroll
+        for (int c = 0; c < QT_HB_MAXC; ++c) {
+            const int e = threadIdx.x + c * 256;
+            if (e < E) {
+                const float d = drow[e];
+                acc[c] = fmaf(d, arow[hcol[c]], acc[c]);
+                atomicAdd(&hs[r][hcol[c]], d * bcol[c]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * H; i += 256) dasum[(r0 + i / H) * H + i % H] = hs[i / H][i % H];
+#pragma unroll
+    for (int c = 0; c < QT_HB_MAXC; ++c) {
+        const int e = threadIdx.x + c * 256;
+        if (e < E) atomicAdd(dbv + e, acc[c]);
+    }
+}
+extern "C" int qt_headbias_bwd(void* stream, const float* dout, long ld, const float* asum, const float* bv, long rows, int E, int H,
+                               float* dasum, float* dbv, int dbv_accumulate) {
+    QT_CHECK_ARG(dout && asum && bv && dasum && dbv && rows > 0 && E > 0 && H > 0 && E % H == 0 && H <= 32 && E <= 256 * QT_HB_MAXC,
+                 "qt_headbias_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!dbv_accumulate) {
+        hipError_t e = qt_zero_1d(dbv, E, st);
+        if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_headbias_bwd: zeroing: %s", hipGetErrorString(e));
+    }
+    const long blocks = (rows + QT_HB_ROWS - 1) / QT_HB_ROWS;
+    QT_CHECK_ARG(blocks < (1L << 31), "qt_headbias_bwd: too many rows");
+    hipLaunchKernelGGL(qt_headbias_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dout, ld, asum, bv, rows, E, E / H, H, dasum, dbv);
+    QT_CHECK_LAUNCH("qt_headbias_bwd");
+    return QT_OK;
+}
+
 // ---- feature shards stored as fp16: widen to the fp32 the path computes in -----------
 // (the reference casts on the host, src/trainutils.py:223-250: `.float()` after `.to(device)`)
 __global__ __launch_bounds__(256) void qt_cast_f16_f32_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, long n8, long n) {

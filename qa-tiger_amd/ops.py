@@ -349,6 +349,16 @@ def tag_amax(t: Tensor, rec: Tensor) -> None:
     t._qt_amax = (rec, t._version)
 
 
+def _retag(t: Optional[Tensor], rec: Optional[Tensor]) -> None:
+    """After an in-place accumulation into `t` by a raw kernel: replace its max|x| tag by the new record, or void it."""
+    if t is None:
+        return
+    if rec is not None:
+        tag_amax(t, rec)
+    elif hasattr(t, '_qt_amax'):
+        del t._qt_amax
+
+
 use_amax_tags = True     # False: every consumer measures max|dY| itself (A/B and debugging of the tag protocol)
 
 
@@ -534,10 +544,11 @@ def _param_rows(t: Tensor):
     if getattr(t, '_qt_gv', None) is not None:
         return t, 0, (t.shape[0] if t.dim() > 0 else 1)
     base = t._base
-    # (row ranges of MATRICES only: the q | k | v blocks of a packed in-projection weight each have an in-place producer; the
-    # blocks of its bias do not all have one, and a gradient that arrives half in place, half through autograd would have to
-    # wait for the end of the backward pass before its bucket may be reduced)
-    if base is None or getattr(base, '_qt_gv', None) is None or t.dim() != 2 or base.dim() != 2 \
+    # (row ranges of matrices AND of vectors: the q | k | v blocks of a packed in-projection weight and of its bias.  A block without an
+    # in-place producer — b_v of a folded attention goes through a small autograd expression, b_k of one gets no gradient at all —
+    # arrives through AccumulateGrad or not at all; the post-accumulate hook, which runs once every use of the parameter has run its
+    # backward, then completes the parameter: train.GradSync._make_hook)
+    if base is None or getattr(base, '_qt_gv', None) is None or t.dim() != base.dim() or t.dim() not in (1, 2) \
             or t.shape[1:] != base.shape[1:] or t.stride() != base.stride() or not base.is_contiguous():
         return None
     inner = 1
@@ -549,9 +560,13 @@ def _param_rows(t: Tensor):
     return base, off // inner, t.shape[0]
 
 
-def _claim_grad_view(param: Tensor):
+def _claim_grad_view(param: Tensor, additive: bool = False):
     """The slice of the flat gradient buffer a producer may write `param`'s gradient into, or None (not a FlatParams parameter,
-    already claimed this step — a shared weight's second use —, or an overlapping row range)."""
+    already claimed this step — a shared weight's second use —, or an overlapping row range).
+    additive=True: the producer ACCUMULATES into the slice (the buffer was zeroed at the start of the step).  Such a producer may also
+    take rows that an earlier producer of this step has written — the second use of a shared weight (QstGrounding runs twice per
+    forward, net.py:136-138) adds its share in place instead of sending it through autograd's AccumulateGrad; an overwriting
+    producer (additive=False) still needs rows nobody has touched."""
     pr = _param_rows(param)
     if pr is None:
         return None
@@ -563,7 +578,8 @@ def _claim_grad_view(param: Tensor):
     if not whole and not direct_grads:           # a row range can only be handed over in place (autograd wants the full-size gradient)
         return None
     ent = _claimed_rows.get(id(base))
-    if id(base) in grad_claims or (ent is not None and any(r0 < b and a < r0 + rows for a, b in ent[2])):
+    shared_ok = additive and direct_grads and grads_prezeroed
+    if not shared_ok and (id(base) in grad_claims or (ent is not None and any(r0 < b and a < r0 + rows for a, b in ent[2]))):
         return None
     if whole:
         grad_claims.add(id(base))
@@ -577,10 +593,12 @@ def _unclaim(param: Tensor) -> None:
     pr = _param_rows(param)
     if pr is not None:
         base, r0, rows = pr
-        grad_claims.discard(id(base))
         ent = _claimed_rows.get(id(base))
         if ent is not None and (r0, r0 + rows) in ent[2]:
             ent[2].remove((r0, r0 + rows))
+        n_rows = base.shape[0] if base.dim() > 0 else 1
+        if ent is None or not any(a == 0 and b == n_rows for a, b in ent[2]):      # (an additive claim may sit on top of an earlier whole claim)
+            grad_claims.discard(id(base))
 
 
 def _grad_written(param: Tensor, view: Tensor):
@@ -598,6 +616,28 @@ def _grad_written(param: Tensor, view: Tensor):
     if ent[1] >= (base.shape[0] if base.dim() > 0 else 1) and _fwd_use_rows.get(id(base)) == ent[1] and grad_ready_cb is not None:
         grad_ready_cb(base)
     return None
+
+
+class GradSink:
+    """One gradient buffer for a tensor with several consumers.  Autograd sums the gradients of a multi-consumer tensor with one
+    elementwise add per extra consumer ([2B T, D] rows in AVQCrossAttn: the stacked input feeds three in-projections and the residual of
+    norm1 — three adds of 94 MB each at the primary config).  With `share_grad(x)` the consumers that know how (LinearFn's dX GEMM,
+    the residual + LayerNorm backward) cooperate instead: the FIRST of them to run backward hands autograd its gradient tensor as
+    usual and parks it here; every later one ACCUMULATES into that memory (GEMM epilogue `accumulate`) and hands autograd None.
+    Autograd only moves the first tensor into the producer's input buffer and reads it when the producer's backward runs — after all
+    consumers, by its own dependency count — so the sum is complete by then.  The generalisation of GradLink to any consumer order."""
+    __slots__ = ('buf', 'holder')
+
+    def __init__(self):
+        self.buf = None          # [rows, cols] view of the parked gradient
+        self.holder = None       # the tensor object autograd carries (re-tagged with max|sum| by accumulating producers)
+
+
+def share_grad(x: Tensor) -> Tensor:
+    """Mark an activation whose gradient contributions should meet in one buffer (see GradSink); returns x."""
+    if x.requires_grad and torch.is_grad_enabled():
+        x._qt_sink = GradSink()
+    return x
 
 
 class GradLink:
@@ -641,7 +681,7 @@ def weight_image(weight: Tensor) -> Optional[SplitImage]:
                 flat.refresh_images()
         o = base._qt_flat_off
         img = SplitImage(flat.img[o:o + base.numel()].view(rows_b, cols), rows_b, cols, base._qt_amax_view)
-    elif _capturing():                               # rebuilt inside the graph: replays follow the weights
+    elif base.is_cuda and _capturing():              # rebuilt inside the graph: replays follow the weights
         with torch.no_grad():
             img = _captured(('wimg', id(base)), lambda: split_image(base.detach(), scaled=True, keep=True))
     else:
@@ -683,14 +723,26 @@ def weight_image_fp8(weight: Tensor) -> Optional[SplitImage]:
     return SplitImage(img.data[r0:r0 + weight.shape[0]], weight.shape[0], cols, img.amax)
 
 
+pass_epoch = 0             # bumped at the start of every model forward (new_pass): activation-side caches never outlive one pass
+
+
+def new_pass() -> None:
+    """Start of a model forward.  Operand images / max records cached on activation tensors are shared by the layers of ONE pass (the three
+    in-projections that read the same rows, ...) and must not survive it: a caller that feeds the same input tensor object to every step
+    (a benchmark loop on one synthetic batch) would otherwise skip the split of its 880 MB patch features from the second step on —
+    work a real training loop, whose batches are new tensors, does every step."""
+    global pass_epoch
+    pass_epoch += 1
+
+
 def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
     if _capturing():                               # in the graph, shared within the capture only
         return _captured(('ximg8', id(x), x._version, tuple(x2.shape)), lambda: (quant_fp8(x2.detach(), keep=True), x))[0]
     cached = getattr(x, '_qt_img8', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
+    if cached is not None and cached[0] == (x._version, x.data_ptr(), pass_epoch) and cached[1].data.shape == x2.shape:
         return cached[1]
-    img = quant_fp8(x2.detach(), keep=True)        # cached on the tensor object
-    x._qt_img8 = ((x._version, x.data_ptr()), img)
+    img = quant_fp8(x2.detach(), keep=True)        # cached on the tensor object for the rest of this pass
+    x._qt_img8 = ((x._version, x.data_ptr(), pass_epoch), img)
     return img
 
 
@@ -706,13 +758,13 @@ def input_image(x: Tensor, x2: Tensor) -> SplitImage:
                 return split_image(x2.detach(), scaled=am is not None, amax=am), x
         return _captured(('ximg', id(x), x._version, tuple(x2.shape)), make)[0]
     cached = getattr(x, '_qt_img', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()) and cached[1].data.shape == x2.shape:
+    if cached is not None and cached[0] == (x._version, x.data_ptr(), pass_epoch) and cached[1].data.shape == x2.shape:
         return cached[1]
     with torch.no_grad():
         # robust-range mode: activations beyond fp16's range are scaled by their max|x| first (act_amax); by default the parts are unscaled
         am = act_amax(x, x2)
         img = split_image(x2.detach(), scaled=am is not None, amax=am)
-    x._qt_img = ((x._version, x.data_ptr()), img)
+    x._qt_img = ((x._version, x.data_ptr(), pass_epoch), img)
     return img
 
 
@@ -736,6 +788,7 @@ def weight_amax(weight: Tensor) -> Optional[Tensor]:
     def measure():
         with torch.no_grad():
             return amax_of(base.detach().reshape(-1, base.shape[-1]) if base.dim() > 1 else base.detach().reshape(1, -1), keep=True)
+    _dev(base)                                      # (a CPU tensor fails here, loudly, before any device query)
     if _capturing():
         return _captured(('wamax', id(base)), measure)
     key = (base._version, weights_epoch, base.data_ptr())
@@ -753,10 +806,10 @@ def act_amax(x: Tensor, x2: Tensor) -> Optional[Tensor]:
     if _capturing():
         return _captured(('xamax', id(x), x._version), lambda: (amax_of(x2.detach(), keep=True), x))[0]
     cached = getattr(x, '_qt_xamax', None)
-    if cached is not None and cached[0] == (x._version, x.data_ptr()):
+    if cached is not None and cached[0] == (x._version, x.data_ptr(), pass_epoch):
         return cached[1]
     am = amax_of(x2.detach(), keep=True)           # read again by the backward's dW GEMM: not a pooled slot
-    x._qt_xamax = ((x._version, x.data_ptr()), am)
+    x._qt_xamax = ((x._version, x.data_ptr(), pass_epoch), am)
     return am
 
 
@@ -776,6 +829,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, drop_p: float, seed: int,
                 residual: Optional[Tensor], grad_premasked: bool, link: Optional[GradLink] = None):
         ctx.link = link
+        ctx.sink = getattr(x, '_qt_sink', None) if link is None else None
         shape = x.shape
         x2 = as2d(x)
         y = None
@@ -833,7 +887,7 @@ class LinearFn(torch.autograd.Function):
             n_out, k_in = weight.shape
             bgv = None
             if want_db:
-                bgv = _claim_grad_view(b_param)
+                bgv = _claim_grad_view(b_param, additive=True)       # (the column sums are accumulated whenever the slice is a claimed one)
                 db = bgv[:] if bgv is not None else torch.empty((n_out,), device=g.device, dtype=torch.float32)
             gam = grad_amax(dy, g)                          # measured by dY's producer when it could (attention / LayerNorm / mask kernels)
             gimg = split_image(g, scaled=gam is None, amax=gam, colsum=db, colsum_accumulate=bgv is not None and grads_prezeroed)
@@ -841,6 +895,7 @@ class LinearFn(torch.autograd.Function):
                 db = _grad_written(b_param, bgv)
             wimg = ctx.wimg
             ximg = SplitImage(x2, x2.shape[0], x2.shape[1], ctx.xam) if ctx.dw_on_image else None
+            sink = ctx.sink
             if ctx.needs_input_grad[0]:
                 # max|dX| is measured by the epilogue that stores it and rides on the tensor autograd hands to dX's consumer
                 cam = new_amax(g.device)
@@ -851,6 +906,11 @@ class LinearFn(torch.autograd.Function):
                     if link.res is not None and amax_tag(acc) is not None:
                         tag_amax(link.res, cam)         # dx stays None: the sum lives in the residual gradient
                     link.buf = link.res = None
+                elif sink is not None and sink.buf is not None and sink.buf.shape == (g.shape[0], k_in):
+                    acc = gemm_ps(gimg, wimg, b_kslow=True, out=sink.buf, accumulate=True, c_amax=cam)     # dx stays None: an earlier consumer's gradient holds the sum
+                    if acc is None:
+                        raise _lib.QTError('qt_gemm_ps refused a dX shape its forward accepted')
+                    _retag(sink.holder, cam if amax_tag(acc) is not None else None)
                 else:
                     dx2 = gemm_ps(gimg, wimg, b_kslow=True, c_amax=cam)
                     if dx2 is None:
@@ -858,8 +918,10 @@ class LinearFn(torch.autograd.Function):
                     dx = dx2.reshape(shape)
                     if amax_tag(dx2) is not None:
                         tag_amax(dx, cam)
+                    if sink is not None and sink.buf is None:
+                        sink.buf, sink.holder = dx2, dx
             if ctx.needs_input_grad[1]:
-                wgv = _claim_grad_view(w_param)
+                wgv = _claim_grad_view(w_param, additive=True)
                 # a claimed slice of the zeroed flat gradient buffer is accumulated into: no zeroing launch in front of a split-K GEMM
                 if ctx.dw_on_image:
                     dw = gemm_ps(gimg, ximg, a_kslow=True, b_kslow=True, out=None if wgv is None else wgv[:],
@@ -873,6 +935,7 @@ class LinearFn(torch.autograd.Function):
                     dw = _grad_written(w_param, wgv)
         else:
             gam = grad_amax(dy, g)                          # max|dY|: the gradient operand's scale for both GEMMs
+            sink = ctx.sink
             if ctx.needs_input_grad[0]:
                 if link is not None and not has_res and link.buf is not None and link.buf.shape == (g.shape[0], weight.shape[1]):
                     # dx stays None; the sum's max|.| is measured by the epilogue that writes it and rides on the residual gradient
@@ -881,14 +944,25 @@ class LinearFn(torch.autograd.Function):
                     if cam is not None and link.res is not None:
                         tag_amax(link.res, cam)
                     link.buf = link.res = None
+                elif sink is not None and sink.buf is not None and sink.buf.shape == (g.shape[0], weight.shape[1]):
+                    gemm(g, weight, trans_b=False, mode=precision['bwd'], out=sink.buf, accumulate=True, a_amax=gam, b_amax=ctx.wam)
+                    _retag(sink.holder, None)               # (the parked gradient grew: whoever consumes it measures it again)
                 else:
-                    dx = gemm(g, weight, trans_b=False, mode=precision['bwd'], a_amax=gam, b_amax=ctx.wam).reshape(shape)
+                    dx2 = gemm(g, weight, trans_b=False, mode=precision['bwd'], a_amax=gam, b_amax=ctx.wam)
+                    dx = dx2.reshape(shape)
+                    if sink is not None and sink.buf is None:
+                        sink.buf, sink.holder = dx2, dx
             if ctx.needs_input_grad[1]:
                 bgv = None
+                # (claims are additive only when BOTH gradients can be accumulated in place: one GEMM launch has one `accumulate` flag)
                 if want_db:                                 # bias gradient rides on the dW GEMM (it streams g anyway)
-                    bgv = _claim_grad_view(b_param)
+                    bgv = _claim_grad_view(b_param, additive=True)
                     db = bgv[:] if bgv is not None else torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
-                wgv = _claim_grad_view(w_param)
+                wgv = _claim_grad_view(w_param, additive=(db is None or bgv is not None))
+                if wgv is None and bgv is not None:         # the weight's slice was not available: the bias goes through autograd too
+                    _unclaim(b_param)
+                    bgv = None
+                    db = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32)
                 inplace = grads_prezeroed and wgv is not None and (db is None or bgv is not None)
                 dw = gemm(g, x2, trans_a=True, trans_b=False, mode=precision['bwd'], a_colsum=db, a_amax=gam,
                           b_amax=ctx.xam if precision['bwd'] == 'f16x3' else None,
@@ -1169,6 +1243,38 @@ class FoldAttnFn(torch.autograd.Function):
         return du_out, dx_out, None, None, None, None, None, None, None, None, None
 
 
+class HeadBiasFn(torch.autograd.Function):
+    """out[m, e] = o[m, e] + asum[m, head(e)] * b_v[e]  (include/qatiger.h qt_headbias_fwd): the value bias of a folded attention."""
+
+    @staticmethod
+    def forward(ctx, o: Tensor, asum: Tensor, bv: Tensor, H: int):
+        o2 = as2d(o)
+        asum2 = asum.contiguous()
+        _dev(o2, asum2, bv)
+        _note_use(bv)
+        rows, E = o2.shape
+        out = torch.empty((rows, E), device=o2.device, dtype=torch.float32)
+        _lib.check(_lib.load().qt_headbias_fwd(_stream(), _ptr(o2), _ld(o2), _ptr(asum2), _ptr(bv), rows, E, H, _ptr(out), E), 'qt_headbias_fwd')
+        ctx.save_for_backward(asum2, bv)
+        ctx.H, ctx.bv_obj, ctx.o_shape = H, bv, o.shape
+        return out.reshape(o.shape)
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        asum2, bv = ctx.saved_tensors
+        d2 = as2d(dout)
+        rows, E = d2.shape
+        dasum = torch.empty_like(asum2)
+        bgv = _claim_grad_view(ctx.bv_obj, additive=True) if (ctx.needs_input_grad[2] and grads_prezeroed) else None
+        dbv = bgv[:] if bgv is not None else torch.empty((E,), device=d2.device, dtype=torch.float32)
+        _lib.check(_lib.load().qt_headbias_bwd(_stream(), _ptr(d2), _ld(d2), _ptr(asum2), _ptr(bv), rows, E, ctx.H, _ptr(dasum), _ptr(dbv),
+                                               int(bgv is not None)), 'qt_headbias_bwd')
+        if bgv is not None:
+            dbv = _grad_written(ctx.bv_obj, bgv)
+        # d o = d out: the same tensor object goes on (its max|dY| tag with it)
+        return dout, (dasum if ctx.needs_input_grad[1] else None), (dbv if ctx.needs_input_grad[2] else None), None
+
+
 def folded_attention(q: Tensor, x: Tensor, mha, n_items: int, Lq: int, Lk: int, u_is: int, u_rs: int,
                      drop_p: float, seed: int) -> Tensor:
     """MHA(query rows q (already q-projected, [rows, E]), key = value = raw rows x [n_items*Lk, E]) WITHOUT the
@@ -1180,10 +1286,12 @@ def folded_attention(q: Tensor, x: Tensor, mha, n_items: int, Lq: int, Lk: int, 
     u = HeadExpandFn.apply(q, W[E:2 * E], H)                                    # W_k folded into the query
     c, asum = FoldAttnFn.apply(u, x, n_items, H, Lq, Lk, u_is, u_rs, 1.0 / math.sqrt(dh), drop_p, seed)
     o = HeadContractFn.apply(c, W[2 * E:], H)                                   # W_v after the weighted sum
-    # + b_v,h * sum_p a_h[p]   (sum = 1 unless attention-probability dropout is active): wb[e, h] = b_v[e] * [e belongs to head h]
-    sel = getattr(mha, '_qt_head_sel', None)
-    if sel is None or sel.device != q.device or sel.shape != (E, H):      # constant 0/1 selector, built once per module (was an arange +
-        sel = (torch.arange(E, device=q.device)[:, None] // dh == torch.arange(H, device=q.device)[None, :]).to(b.dtype)   # compare per call)
+    # + b_v,h * sum_p a_h[p]   (sum = 1 unless attention-probability dropout is active)
+    if dh % 4 == 0 and H <= 32 and E <= 2048:
+        return HeadBiasFn.apply(o, asum, b[2 * E:], H)
+    sel = getattr(mha, '_qt_head_sel', None)                              # generic head widths: a K = H GEMM on wb[e, h] = b_v[e] * [e belongs to head h]
+    if sel is None or sel.device != q.device or sel.shape != (E, H):
+        sel = (torch.arange(E, device=q.device)[:, None] // dh == torch.arange(H, device=q.device)[None, :]).to(b.dtype)
         mha._qt_head_sel = sel
     wb = b[2 * E:, None] * sel                                            # [E, H]; differentiable in b_v
     return linear(asum, wb, None, residual=o)
@@ -1219,6 +1327,7 @@ class AddLayerNormFn(torch.autograd.Function):
                                        LN_EPS, _ptr(y), D, int(relu_out), _ptr(xhat), _ptr(rstd))
         _lib.check(rc, 'qt_add_ln_fwd')
         ctx.save_for_backward(gamma, xhat, rstd, y if relu_out else None)
+        ctx.sinks = [getattr(x, '_qt_sink', None) for x in xs]
         ctx.params = (gamma, beta)                  # the Parameter objects (for the flat-gradient claim in backward)
         ctx.cfg = (relu_out, drop_p, tuple(scales), tuple(drops), tuple(sds), [x.shape for x in xs])
         return y.reshape(xs[0].shape)
@@ -1237,8 +1346,8 @@ class AddLayerNormFn(torch.autograd.Function):
         acc_params = 0
         ggv = bgv = None
         if grads_prezeroed:                          # accumulate straight into the parameters' slices of the (zeroed) flat gradient buffer
-            ggv = _claim_grad_view(ctx.params[0])
-            bgv = _claim_grad_view(ctx.params[1]) if ggv is not None else None
+            ggv = _claim_grad_view(ctx.params[0], additive=True)
+            bgv = _claim_grad_view(ctx.params[1], additive=True) if ggv is not None else None
         if ggv is not None and bgv is not None:
             dgamma, dbeta, acc_params = ggv[:], bgv[:], 1
         else:
@@ -1262,6 +1371,9 @@ class AddLayerNormFn(torch.autograd.Function):
         for o_, a_ in zip(outs, ams):
             if o_ is not None and a_ is not None:
                 tag_amax(o_, a_)
+        for d, o_, sk in zip(dxs, outs, ctx.sinks):  # the residual's gradient is usually the first contribution to its tensor: park it
+            if sk is not None and sk.buf is None and d is not None:
+                sk.buf, sk.holder = d, o_
         if acc_params:
             dgamma, dbeta = _grad_written(ctx.params[0], ggv), _grad_written(ctx.params[1], bgv)
         return (dgamma, dbeta, None, None, None, None, None, *outs)

@@ -97,7 +97,8 @@ class AVQCrossAttn(nn.Module):
         H = self.nhead
         p = self.dropout.p if self.training else 0.0
         nxt = ops.seeds.next
-        x = torch.cat([src_q, src_v], dim=0)                                   # [2B,T,D]: items 0..B-1 audio, B..2B-1 video
+        # [2B,T,D]: items 0..B-1 audio, B..2B-1 video; its gradient (three in-projection dX GEMMs + the residual of norm1) meets in one buffer
+        x = ops.share_grad(torch.cat([src_q, src_v], dim=0))
         # self-attention (packed QKV, each item attends to itself)
         qkv = ops.linear(x, *_mha_proj(self.slf_attn, 'qkv'))
         o_s = ops.attention(qkv, None, AttnSpec(2 * B, 2 * B, 0, H, T, T, D, 0, D, 2 * D), p, nxt())
@@ -114,8 +115,8 @@ class AVQCrossAttn(nn.Module):
         a_s = ops.linear(o_s, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias)
         a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias)
         a_q = ops.linear(o_q, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias)
-        x = ops.add_layer_norm([x, a_s, a_c, a_q], self.norm1.weight, self.norm1.bias,
-                               drops=[False, True, True, True], drop_p=p)
+        x = ops.share_grad(ops.add_layer_norm([x, a_s, a_c, a_q], self.norm1.weight, self.norm1.bias,
+                                              drops=[False, True, True, True], drop_p=p))      # feeds linear1 and the residual of norm2
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p, seed=nxt())
         f = ops.linear(h, self.linear2.weight, self.linear2.bias)
         x = ops.add_layer_norm([x, f], self.norm2.weight, self.norm2.bias, drops=[False, True], drop_p=p)

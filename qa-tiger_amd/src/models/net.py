@@ -78,13 +78,14 @@ class QA_TIGER(nn.Module):
         return quest, words, audio, video, patch
 
     def forward(self, reshaped_data: Dict[str, Tensor]):
+        ops.new_pass()                          # operand images cached on activations (and on the INPUT tensors) live for one pass only
         quest, words, audio, video, patch = self.sub_forward(reshaped_data, prefix='')
         if patch is None:
             raise KeyError("QA_TIGER needs reshaped_data['patch'] [B,T,P,patch_dim] (reference net.py:124)")
         audio = self.audio_proj(audio)
         video = self.video_proj(video)
         words = self.words_proj(words)
-        quest = self.quest_proj(quest)
+        quest = ops.share_grad(self.quest_proj(quest))          # four Linear consumers (two aggregators, two grounding calls): one gradient buffer
         patch = self.patch_proj(patch)
         audio, video = self.crs_attn(audio, video, words)
         patch = self.patch_selecter(patch, audio, video)

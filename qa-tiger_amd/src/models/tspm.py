@@ -212,6 +212,7 @@ class TSPM(nn.Module):
         self.last = {}
 
     def forward(self, reshaped_data: Dict[str, Tensor]):
+        ops.new_pass()                          # operand caches on activations / input tensors live for one pass only
         audio, visual, patch = reshaped_data['audio'], reshaped_data['video'], reshaped_data['patch']
         question, prompt = reshaped_data['quest'], reshaped_data['prompt']
         if not (torch.is_tensor(question) and question.is_floating_point()):

@@ -153,9 +153,9 @@ class GradSync:
                 if p.grad.data_ptr() != gv.data_ptr():   # already in place when the producing GEMM wrote into gv
                     gv.copy_(p.grad)
                 p.grad = gv                        # later accumulations (shared weights) add in place
-            ent = ops._claimed_rows.get(id(p))
-            if ent is not None and 0 < ent[1] < (p.shape[0] if p.dim() > 0 else 1):
-                return                             # part of this gradient is written in place by producers autograd does not see: finish() fires its bucket
+            # AccumulateGrad (and this hook) runs once EVERY use of the parameter has run its backward — autograd's dependency count
+            # includes the producers that wrote their share in place and returned None — so the gradient is complete here whatever mix
+            # of in-place row blocks and autograd-delivered parts it is made of
             self._mark(i)
         return hook
 
