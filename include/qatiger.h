@@ -89,6 +89,14 @@ int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
                 float* o, long ldo, long o_is, long o_rs,
                 int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
                 float scale, float drop_p, unsigned long long seed, float* lse);
+/* The same with the option of writing o as a SPLIT IMAGE (qt_split_f16's format, unscaled; row pitch ld_img_bytes, a multiple of 128)
+ * for the out-projection GEMM that is its only consumer (qt_gemm_ps): returns 1 when the image was written INSTEAD of the fp32 rows
+ * (MFMA kernels: every attention shape of the path), 0 when the fp32 rows were written as by qt_attn_fwd. */
+int qt_attn_fwd_img(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                    const float* k, long ldk, const float* v, long ldv, long kv_is,
+                    float* o, long ldo, long o_is, long o_rs,
+                    int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                    float scale, float drop_p, unsigned long long seed, float* lse, void* o_img, long ld_img_bytes);
 int qt_attn_bwd(void* stream, const float* q, long ldq, long q_is, long q_rs,
                 const float* k, long ldk, const float* v, long ldv, long kv_is,
                 const float* d_o, long lddo, long do_is, long do_rs,

@@ -25,6 +25,7 @@ struct AttnArgs {
     const float* k; long ldk;
     const float* v; long ldv; long kv_is;      // kv rows of an item are consecutive
     float* o; long ldo, o_is, o_rs;
+    char* o_img; long ld_img;   // nullable: the MFMA forward writes o as a SPLIT IMAGE (gemm_plane.hip: per row and 32 columns one 128-byte line [32 x fp16 hi | 32 x fp16 lo], unscaled) instead of fp32 rows
     int n_items, n_kv, kv_shift, H, Lq, Lk, dh;
     float scale, drop_p, inv_keep;
     unsigned long long seed; const unsigned long long* salt;     // salt: qt_common.h "per-step dropout salt"
@@ -338,6 +339,32 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int w
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][j], vrow[dt * 16], oacc[dt], 0, 0, 0);
             }
         }
+        if (p.o_img) {
+            // The only consumer of o is the out-projection GEMM, which reads split images: write the image here and the fp32 rows never
+            // exist (no split pass: 0.25 ms for the 660 MB patch-attention output).  A 16-lane group holds 16 consecutive columns of a row;
+            // lanes pair up: the even lane stores the two hi halves (4 bytes), the odd lane the two lo halves — one 4-byte store per lane
+            // and element, as before.
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qo = q0 + g * 4 + j;
+                char* irow = p.o_img + ((long)n * p.o_is + (long)min(qo, Lq - 1) * p.o_rs) * p.ld_img;
+#pragma unroll
+                for (int dt = 0; dt < DC; ++dt) {
+                    const float x = oacc[dt][j];
+                    const _Float16 hi = (_Float16)x;
+                    const _Float16 lo = (_Float16)(x - (float)hi);
+                    const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, (c & 1) ? lo : hi);
+                    const unsigned other_hi = (unsigned)__builtin_bit_cast(unsigned short, hi), other_lo = (unsigned)__builtin_bit_cast(unsigned short, lo);
+                    // even lane needs its right neighbour's hi, odd lane its left neighbour's lo
+                    const unsigned got = (unsigned)__shfl_xor((int)((c & 1) ? other_hi : other_lo), 1, 64);   // what the PARTNER needs: odd sends hi, even sends lo
+                    const unsigned word = (c & 1) ? (got | (mine << 16)) : (mine | (got << 16));
+                    const int col = hd * DH + dt * 16 + (c & ~1);                 // first column of the pair
+                    if (qo < Lq)
+                        *reinterpret_cast<unsigned*>(irow + (long)(col >> 5) * 128 + ((c & 1) ? 64 : 0) + (col & 31) * 2) = word;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int qo = q0 + g * 4 + j;
@@ -346,6 +373,7 @@ __global__ __launch_bounds__(256) void qt_attn_fwd_mfma_kernel(AttnArgs p, int w
 #pragma unroll
                 for (int dt = 0; dt < DC; ++dt) orow[dt * 16] = oacc[dt][j];
             }
+        }
         }
     }
 }
@@ -1064,7 +1092,8 @@ static int attn_fwd_impl(void* stream, const float* q, long ldq, long q_is, long
                          const float* k, long ldk, const float* v, long ldv, long kv_is,
                          float* o, long ldo, long o_is, long o_rs,
                          int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
-                         float scale, float drop_p, unsigned long long seed, float* lse, int causal) {
+                         float scale, float drop_p, unsigned long long seed, float* lse, int causal,
+                         void* o_img = nullptr, long ld_img = 0) {
     QT_CHECK_ARG(q && k && v && o, "qt_attn_fwd: null pointer");
     QT_CHECK_ARG(n_items > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dh > 0, "qt_attn_fwd: bad sizes");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_attn_fwd: drop_p=%f", drop_p);
@@ -1078,8 +1107,10 @@ static int attn_fwd_impl(void* stream, const float* q, long ldq, long q_is, long
     if (causal && path == QT_ATTN_MFMA) path = QT_ATTN_STREAM;
     if (path == QT_ATTN_MFMA) {
         int rc;
+        const bool img = o_img != nullptr && (H * dh) % 32 == 0 && dh % 2 == 0 && ld_img % 128 == 0 && (((uintptr_t)o_img) & 15u) == 0;
+        if (img) { a.o_img = (char*)o_img; a.ld_img = ld_img; }
         QT_ATTN_DISPATCH(launch_fwd_mfma, a, (hipStream_t)stream, rc);
-        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return QT_OK; }
+        if (rc == 0) { QT_CHECK_LAUNCH("qt_attn_fwd(mfma)"); return img ? 1 : QT_OK; }
         QT_FAIL(QT_ERR_RUNTIME, "qt_attn_fwd: no MFMA kernel instance for d_h=%d", dh);
     }
     if (path == QT_ATTN_STREAM) {
@@ -1114,6 +1145,18 @@ extern "C" int qt_attn_fwd(void* stream, const float* q, long ldq, long q_is, lo
                            float scale, float drop_p, unsigned long long seed, float* lse) {
     return attn_fwd_impl(stream, q, ldq, q_is, q_rs, k, ldk, v, ldv, kv_is, o, ldo, o_is, o_rs,
                          n_items, n_kv, kv_shift, H, Lq, Lk, dh, scale, drop_p, seed, lse, 0);
+}
+
+// The same, with the option of writing o as a split image (include/qatiger.h qt_split_f16 format, unscaled) for the out-projection GEMM
+// that consumes it: returns 1 when the image was written INSTEAD of the fp32 rows (the MFMA kernels: all shapes of the path), 0 when the
+// fp32 rows were written as by qt_attn_fwd (other kernels; the caller then splits them as before).
+extern "C" int qt_attn_fwd_img(void* stream, const float* q, long ldq, long q_is, long q_rs,
+                               const float* k, long ldk, const float* v, long ldv, long kv_is,
+                               float* o, long ldo, long o_is, long o_rs,
+                               int n_items, int n_kv, int kv_shift, int H, int Lq, int Lk, int dh,
+                               float scale, float drop_p, unsigned long long seed, float* lse, void* o_img, long ld_img_bytes) {
+    return attn_fwd_impl(stream, q, ldq, q_is, q_rs, k, ldk, v, ldv, kv_is, o, ldo, o_is, o_rs,
+                         n_items, n_kv, kv_shift, H, Lq, Lk, dh, scale, drop_p, seed, lse, 0, o_img, ld_img_bytes);
 }
 
 // Causal self-attention, forward only: the frozen CLIP text tower (reference

@@ -749,6 +749,8 @@ def input_image_fp8(x: Tensor, x2: Tensor) -> SplitImage:
 def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     """Split image of an activation (x2 = the [rows, k_in] view of x), made once per tensor object: the layers that read the
     same tensor (the three in-projections of AVQCrossAttn, ...) and the dW GEMM of the backward share it."""
+    if getattr(x, '_qt_is_image', False):           # the producer wrote the image itself (attention output): x IS its image, in or out of a capture
+        return x._qt_img[1]
     if _capturing():
         # the split must be IN the graph (a cached image would freeze the warm-up batch into it) and is shared only within the capture
         # (the tuple keeps x alive, so id(x) stays unique for the capture)
@@ -850,6 +852,9 @@ class LinearFn(torch.autograd.Function):
             if wimg is not None:
                 ximg = input_image(x, x2)
                 y = gemm_ps(ximg, wimg, bias=bias, add=residual, relu=int(relu), drop_p=drop_p, seed=seed)
+        if getattr(x, '_qt_is_image', False) and (y is None or x2.shape[0] < plane_dw_min_rows):
+            raise _lib.QTError('a tensor that holds a split image (attention output written for the pre-split GEMM) reached a Linear layer '
+                               'that reads fp32 rows')
         if y is None:
             ximg = wimg = None
             wam = weight_amax(weight) if weight.shape[1] % 4 == 0 else None
@@ -1014,20 +1019,26 @@ class AttnSpec:
         self.scale = 1.0 / math.sqrt(self.dh)
 
 
-def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int):
+def _attn_fwd(qbuf: Tensor, kvbuf: Tensor, s: AttnSpec, drop_p: float, seed: int, want_img: bool = False):
+    """Returns (o, lse, is_image): with want_img the kernel may write o as a split image (same shape and bytes as the fp32 tensor)."""
     _dev(qbuf, kvbuf)
     o = torch.empty((s.o_rows, s.E), device=qbuf.device, dtype=torch.float32)
     lse = torch.empty((s.n_items * s.H * s.Lq,), device=qbuf.device, dtype=torch.float32)   # used by the streaming path
     f4 = 4
     nbytes = 4.0 * s.E * (2 * s.n_items * s.Lq + 2 * s.n_kv * s.Lk)
-    rc = _launch('attn_fwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_fwd(
-        _stream(), C.c_void_p(qbuf.data_ptr() + s.q_col * f4), _ld(qbuf), s.q_is, s.q_rs,
-        C.c_void_p(kvbuf.data_ptr() + s.k_col * f4), _ld(kvbuf),
-        C.c_void_p(kvbuf.data_ptr() + s.v_col * f4), _ld(kvbuf), s.Lk,
-        _ptr(o), s.E, s.o_is, s.o_rs,
-        s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed), _ptr(lse)))
+    head = lambda: (_stream(), C.c_void_p(qbuf.data_ptr() + s.q_col * f4), _ld(qbuf), s.q_is, s.q_rs,
+                    C.c_void_p(kvbuf.data_ptr() + s.k_col * f4), _ld(kvbuf),
+                    C.c_void_p(kvbuf.data_ptr() + s.v_col * f4), _ld(kvbuf), s.Lk,
+                    _ptr(o), s.E, s.o_is, s.o_rs,
+                    s.n_items, s.n_kv, s.kv_shift, s.H, s.Lq, s.Lk, s.dh, s.scale, float(drop_p), C.c_ulonglong(seed), _ptr(lse))
+    if want_img and s.E % 32 == 0:
+        # one buffer serves both outcomes: the image has the pitch and size of the fp32 tensor (rc 1: it holds the image)
+        rc = _launch('attn_fwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_fwd_img(*head(), _ptr(o), 4 * s.E))
+        _lib.check(0 if rc == 1 else rc, 'qt_attn_fwd_img')
+        return o, lse, rc == 1
+    rc = _launch('attn_fwd', nbytes, (s.n_items, s.Lq, s.Lk, s.E), lambda: _lib.load().qt_attn_fwd(*head()))
     _lib.check(rc, 'qt_attn_fwd')
-    return o, lse
+    return o, lse, False
 
 
 class AttentionFn(torch.autograd.Function):
@@ -1035,12 +1046,19 @@ class AttentionFn(torch.autograd.Function):
     projection outputs.  `kvbuf is None` means packed QKV in `qbuf`."""
 
     @staticmethod
-    def forward(ctx, qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float, seed: int):
+    def forward(ctx, qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float, seed: int, out_image: bool = False):
         qb = as2d(qbuf)
         kb = qb if kvbuf is None else as2d(kvbuf)
-        o, lse = _attn_fwd(qb, kb, spec, drop_p, seed)
-        ctx.save_for_backward(qb, kb if kvbuf is not None else None, o, lse)
+        o, lse, is_img = _attn_fwd(qb, kb, spec, drop_p, seed, want_img=out_image)
+        # (the fp32 o is saved for the streaming backward's delta = rowsum(dO * O) only; the kernels that write an image do not need it)
+        ctx.save_for_backward(qb, kb if kvbuf is not None else None, None if is_img else o, lse)
         ctx.cfg = (spec, drop_p, seed, qbuf.shape, None if kvbuf is None else kvbuf.shape)
+        if is_img:
+            # `o` holds the split image of the attention output, not fp32 rows: it may only feed a Linear on the pre-split path, which
+            # finds the image here (input_image) and checks the flag
+            img = SplitImage(o, o.shape[0], o.shape[1], None)
+            o._qt_img = ((o._version, o.data_ptr(), pass_epoch), img)
+            o._qt_is_image = True
         return o
 
     @staticmethod
@@ -1077,11 +1095,17 @@ class AttentionFn(torch.autograd.Function):
         dq_out = dqb.reshape(qshape)
         if gam is not None:
             tag_amax(dq_out, gam)                      # the in-projection's backward GEMMs scale dY by it (grad_amax)
-        return dq_out, (None if packed else dkb.reshape(kvshape)), None, None, None
+        return dq_out, (None if packed else dkb.reshape(kvshape)), None, None, None, None
 
 
-def attention(qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float = 0.0, seed: int = 0) -> Tensor:
-    return AttentionFn.apply(qbuf, kvbuf, spec, drop_p, seed)
+def attention(qbuf: Tensor, kvbuf: Optional[Tensor], spec: AttnSpec, drop_p: float = 0.0, seed: int = 0, for_linear: Optional[Tuple[int, int]] = None) -> Tensor:
+    """for_linear = (n_out, k_in) of the Linear layer that is the ONLY consumer of the result: when that layer will run on the pre-split
+    GEMM (forward, dX and dW on images) the attention kernel writes its output as the split image directly and the fp32 rows never exist."""
+    img = False
+    if for_linear is not None:
+        rows = spec.o_rows
+        img = _plane_ok(rows, for_linear[0], for_linear[1]) and rows >= plane_dw_min_rows and not robust_range and spec.E == for_linear[1]
+    return AttentionFn.apply(qbuf, kvbuf, spec, drop_p, seed, img)
 
 
 # --------------------------------------------------------------------------- #

@@ -101,15 +101,16 @@ class AVQCrossAttn(nn.Module):
         x = ops.share_grad(torch.cat([src_q, src_v], dim=0))
         # self-attention (packed QKV, each item attends to itself)
         qkv = ops.linear(x, *_mha_proj(self.slf_attn, 'qkv'))
-        o_s = ops.attention(qkv, None, AttnSpec(2 * B, 2 * B, 0, H, T, T, D, 0, D, 2 * D), p, nxt())
+        fl = (D, D)                                                            # each attention output feeds only its out-projection
+        o_s = ops.attention(qkv, None, AttnSpec(2 * B, 2 * B, 0, H, T, T, D, 0, D, 2 * D), p, nxt(), for_linear=fl)
         # cross-modal attention: audio item b reads video item b and vice versa (shift B)
         qkv = ops.linear(x, *_mha_proj(self.crs_attn, 'qkv'))
-        o_c = ops.attention(qkv, None, AttnSpec(2 * B, 2 * B, B, H, T, T, D, 0, D, 2 * D), p, nxt())
+        o_c = ops.attention(qkv, None, AttnSpec(2 * B, 2 * B, B, H, T, T, D, 0, D, 2 * D), p, nxt(), for_linear=fl)
         # question attention: both directions share one words K/V projection
         q = ops.linear(x, *_mha_proj(self.qst_attn, 'q'))
         kv = ops.linear(query, *_mha_proj(self.qst_attn, 'kv'))
         qst_spec, qst_seed = AttnSpec(2 * B, B, 0, H, T, L, D, 0, 0, D), nxt()
-        o_q = ops.attention(q, kv, qst_spec, p, qst_seed)
+        o_q = ops.attention(q, kv, qst_spec, p, qst_seed, for_linear=fl)
         # (kept as [2B*T, D]: add_layer_norm takes any shapes with the same rows; a reshape node between the two would strip the
         # max|dY| tag the LayerNorm backward puts on these layers' gradients)
         a_s = ops.linear(o_s, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias)
@@ -292,7 +293,7 @@ class PatchSelecter(nn.Module):
         # per-frame self-attention over the P patch tokens, residual, no norm (modules.py:688)
         link = ops.GradLink()                                              # d(pp) = residual gradient + in-projection dX, summed inside the dX GEMM
         qkv = ops.linear(pp, *_mha_proj(self.slf_attn, 'qkv'), link=link)
-        o = ops.attention(qkv, None, AttnSpec(BT, BT, 0, H, P, P, D, 0, D, 2 * D), p, nxt())
+        o = ops.attention(qkv, None, AttnSpec(BT, BT, 0, H, P, P, D, 0, D, 2 * D), p, nxt(), for_linear=(D, D))
         psa = ops.linear(o, self.slf_attn.out_proj.weight, self.slf_attn.out_proj.bias, residual=pp, link=link)
         # two queries per frame — row 0 video, row 1 audio (modules.py:692) — stacked as [video; audio]
         y2 = torch.cat([video.reshape(BT, D), audio.reshape(BT, D)], dim=0)

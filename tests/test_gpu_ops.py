@@ -203,6 +203,38 @@ def test_gemm_dropout_epilogue_and_mask_grad(ops):
     assert rel(mg, g * (y > 0) / (1 - p)) < 1e-6
 
 
+@pytest.mark.parametrize('Lq,Lk,n_items,n_kv,shift', [(14, 14, 1024, 1024, 0), (60, 60, 160, 160, 80), (60, 77, 160, 80, 0)])
+def test_attention_writes_split_image_for_its_out_projection(ops, Lq, Lk, n_items, n_kv, shift):
+    """`attention(..., for_linear=(n_out, k_in))`: when the out-projection that consumes the result runs on the pre-split GEMM, the MFMA
+    attention kernel writes the split image itself (qt_attn_fwd_img).  The image is bit-identical to qt_split_f16 of the fp32 output,
+    Linear finds it without a split pass, and forward / backward of attention + Linear match the fp32-rows route."""
+    E, H = 768, 8
+    packed = Lq == Lk and n_kv == n_items
+    spec = ops.AttnSpec(n_items, n_kv, shift, H, Lq, Lk, E, 0, E if packed else 0, 2 * E if packed else E)
+    qkv = rnd(n_items * Lq, 3 * E if packed else E, seed=31).requires_grad_(True)
+    kv = None if packed else rnd(n_kv * Lk, 2 * E, seed=32).requires_grad_(True)
+    w, b = rnd(E, E, seed=33, scale=0.05).requires_grad_(True), rnd(E, seed=34).requires_grad_(True)
+    assert n_items * Lq >= ops.plane_dw_min_rows
+    o_ref = ops.attention(qkv, kv, spec, 0.1, 77)
+    o_img = ops.attention(qkv, kv, spec, 0.1, 77, for_linear=(E, E))
+    assert getattr(o_img, '_qt_is_image', False) and not getattr(o_ref, '_qt_is_image', False)
+    assert torch.equal(o_img.detach().view(torch.int32), ops.split_image(o_ref.detach()).data.view(torch.int32))
+    gy = rnd(n_items * Lq, E, seed=35)
+    outs = []
+    for o in (o_ref, o_img):
+        for t in (qkv, kv, w, b):
+            if t is not None:
+                t.grad = None
+        y = ops.linear(o, w, b)
+        y.backward(gy)
+        outs.append((y.detach().clone(), qkv.grad.clone(), None if kv is None else kv.grad.clone(), w.grad.clone(), b.grad.clone()))
+    for a_, b_ in zip(*outs):
+        if a_ is not None:
+            assert rel(a_, b_) < 2e-6
+    with pytest.raises(Exception, match='split image'):                      # the tensor must never be read as fp32 rows: a layer off the pre-split path refuses it
+        ops.linear(o_img, w[:64].detach(), None)
+
+
 def test_linear_fn_grads(ops):
     x = rnd(5, 7, 96, seed=12).requires_grad_(True)
     w = rnd(130, 96, seed=13, scale=0.1).requires_grad_(True)
