@@ -48,7 +48,7 @@ PEAK_HBM_GBS = 8000.0
 DTYPE = {('f16x3', 'bf16x3'): 'f32 (3xf16 fwd / 3xbf16 bwd split)', ('f16x3', 'f16x3'): 'f32 (3xf16 split, scaled, fwd and bwd)',
          ('fp32', 'fp32'): 'f32', ('bf16x1', 'bf16x1'): 'bf16 products, f32 accumulate'}
 ATTN_MB_FWD_BWD = 59.4                   # q,k,v,o,dO,dq,dk,dv each touched once = 21.6 * 11/4
-PMC_TRAFFIC_FILES = ['r02_pmc_step_traffic.json', 'r01_pmc_step_traffic.json']   # newest first (tools/pmc_step_traffic.sh)
+PMC_TRAFFIC_FILES = ['r03_pmc_step_traffic.json', 'r02_pmc_step_traffic.json', 'r01_pmc_step_traffic.json']   # newest first (tools/pmc_step_traffic.sh)
 
 
 def parse():
