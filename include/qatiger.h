@@ -227,12 +227,16 @@ int qt_split_f16(void* stream, const float* x, long ldx, long R, int C, const fl
  * `accumulate` included), so the next GEMM that takes C as its gradient operand needs no pass of its own; a split-K launch
  * (atomics) cannot know it and returns 2 with the record untouched.
  * Tile height: 256 rows, or 192 / 128 for row-form A operands when the launcher's cost model finds that the shorter tile fills the
- * rounds of the persistent walk better (QT_PS_WMT=2|3|4 in the environment pins it). */
+ * rounds of the persistent walk better (QT_PS_WMT=2|3|4 in the environment pins it).
+ * ws / ws_floats (nullable / 0): a caller-owned workspace.  When the launch splits K (small outputs over a long K: the dW GEMMs) and
+ * split * M * N floats fit, every K split stores its partial tile into its own slab and a second launch sums the slabs into C in a
+ * fixed order — no fp32 atomics, no zeroing launch, bit-reproducible; without a workspace the splits meet in C through atomics. */
 int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
                const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                const float* mask_src, long ld_mask, float mask_scale,
-               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax);
+               float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
+               float* ws, long ws_floats);
 
 /* ---- BASELINE configs[4] ("fp8 MFMA on projection GEMMs"): e4m3 operand images and the GEMM on
  * v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 accumulate, fp32 epilogue).  Outside the 1e-3 parity gate by construction: judged by

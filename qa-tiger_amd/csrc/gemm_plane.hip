@@ -64,6 +64,8 @@ struct PlaneArgs {
     float drop_p; float inv_keep; unsigned long long drop_seed; const unsigned long long* salt;   // salt: qt_common.h "per-step dropout salt"
     int accumulate;
     int split_k, k_per_split, tiles_n, tiles_m;
+    long ws_stride;                  // > 0: split-K through a WORKSPACE — K split z stores its partial tile (plain stores, C^T orientation) at C + z * ws_stride
+                                     // (C = the workspace, ldc = N) and qt_splitk_reduce sums the slabs: no atomics, no zeroing, a fixed summation order
     int debug;                       // QT_PS_DEBUG (profiling probes only): 1 skip the write-out, 2 DMA only for the first step of a tile, 4 no MFMAs
 };
 
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
         // ---- this tile's output coordinates, kept for the epilogue while the NEXT tile's first DMA goes out
         const int em0 = m0, en0 = n0;
         const bool first_split = (ksplit == 0);
+        float* const Cw = p.C + (long)ksplit * p.ws_stride;      // (ws_stride = 0: C itself)
         w += G;
         const bool more = w < total;
         if (more) {
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                         if (has_add) addv[g] = *reinterpret_cast<const float4*>(p.add_src + mc * p.ld_add + nc);
                         if (full) {
                             mskv[g] = p.mask_src ? *reinterpret_cast<const float4*>(p.mask_src + mc * p.ld_mask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
-                            oldv[g] = p.accumulate ? *reinterpret_cast<const float4*>(p.C + mc * p.ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            oldv[g] = p.accumulate ? *reinterpret_cast<const float4*>(Cw + mc * p.ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                     }
                     p_static_for<4>([&](auto Gq) {
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                         }
                         if (m < p.M && n < p.N) {
                             cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                            *reinterpret_cast<float4*>(p.C + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(Cw + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     });
                 });
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                     if (has_add) addv[jt] = *reinterpret_cast<const float4*>(p.add_src + mc * p.ld_add + nc);
                     if (full) {
                         mskv[jt] = p.mask_src ? *reinterpret_cast<const float4*>(p.mask_src + mc * p.ld_mask + nc) : make_float4(1.f, 1.f, 1.f, 1.f);
-                        oldv[jt] = p.accumulate ? *reinterpret_cast<const float4*>(p.C + mc * p.ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        oldv[jt] = p.accumulate ? *reinterpret_cast<const float4*>(Cw + mc * p.ldc + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
                 p_static_for<2 * WNT>([&](auto J) {
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                     }
                     if (m < p.M && n < p.N) {
                         cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                        *reinterpret_cast<float4*>(p.C + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(Cw + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 });
             });
@@ -1070,12 +1073,29 @@ extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int 
 }
 
 
+// Sum of the K-split slabs of a workspace GEMM: C[m, n] (+)= sum_z ws[z][m][n], slabs in a fixed order (deterministic, unlike atomics).
+__global__ __launch_bounds__(256) void qt_splitk_reduce_kernel(const float* __restrict__ ws, int split, long mn, int N, float* __restrict__ C, long ldc, int accumulate) {
+    const long n4 = mn >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 acc = *reinterpret_cast<const float4*>(ws + i * 4);
+        for (int z = 1; z < split; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (long)z * mn + i * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const long e = i * 4, m = e / N;
+        float4* dst = reinterpret_cast<float4*>(C + m * ldc + (e - m * N));          // N % 4 == 0: the four columns share a row
+        if (accumulate) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        *dst = acc;
+    }
+}
+
 // Shared launcher.  fmt 0: fp16 (hi | lo) lines, K step 32;  fmt 1: e4m3 lines, K step 128, row-form operands only.
 static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
                       const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                       float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                       const float* mask_src, long ld_mask, float mask_scale,
-                      float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax) {
+                      float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
+                      float* ws = nullptr, long ws_floats = 0) {
     const int KS = fmt == 1 ? 128 : PBK;
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "%s: bad problem", who);
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "%s: drop_p=%f", who, drop_p);
@@ -1137,16 +1157,23 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
     a.c_amax = split_k > 1 ? nullptr : c_amax;       // partial sums are not the values of C: the caller measures it (return 2)
-    if (split_k > 1 && !accumulate) {
+    // the 16-byte epilogue needs 16-byte aligned rows of C and of every epilogue operand; anything else keeps the dword orientation
+    const bool vec_ok = N % 4 == 0 && ldc % 4 == 0 && qt_aligned16(C) && (!bias || qt_aligned16(bias)) &&
+                        (!add_src || (qt_aligned16(add_src) && ld_add % 4 == 0)) && (!mask_src || (qt_aligned16(mask_src) && ld_mask % 4 == 0));
+    // Split-K through a workspace when the caller gave one that holds the slabs (dW GEMMs: small outputs over a long K): every K split
+    // stores its partial tile with plain 16-byte stores and one pass sums the slabs into C — 768x768x30720 at split 28: 16.5 M fp32
+    // atomics (61 us at the L2's ~270 per ns) become 66 MB of stores plus a 66 MB read, no zeroing launch, and the sum has a fixed order.
+    const bool use_ws = split_k > 1 && vec_ok && fmt == 0 && plain_epilogue && !bias && !add_src && ws && qt_aligned16(ws) &&
+                        (long)split_k * M * N <= ws_floats && !(getenv("QT_PS_ATOMIC"));
+    a.ws_stride = 0;
+    if (use_ws) { a.C = ws; a.ldc = N; a.ws_stride = (long)M * N; a.accumulate = 0; }
+    else if (split_k > 1 && !accumulate) {
         hipError_t e = qt_zero_2d(C, ldc, M, N, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "%s: zeroing C: %s", who, hipGetErrorString(e));
     }
     const long total_work = tiles * split_k;
     dim3 grid((unsigned)(total_work > slots ? slots : total_work));
-    // the 16-byte epilogue needs 16-byte aligned rows of C and of every epilogue operand; anything else keeps the dword orientation
-    const bool vec_ok = N % 4 == 0 && ldc % 4 == 0 && qt_aligned16(C) && (!bias || qt_aligned16(bias)) &&
-                        (!add_src || (qt_aligned16(add_src) && ld_add % 4 == 0)) && (!mask_src || (qt_aligned16(mask_src) && ld_mask % 4 == 0));
-    const bool swap = split_k == 1 && vec_ok;
+    const bool swap = (split_k == 1 || use_ws) && vec_ok;
     // MFMA shape of the fp16 path: the 16x16x32 form by default (the chip holds a higher clock on it: 215040x2304x768 2.04 -> 1.88 ms on
     // the same images, tools/ab_mfma_shape.py); QT_PS_MF=0 selects the 32x32x16 form (A/B runs; read per call)
     int mf = 1;
@@ -1155,6 +1182,12 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);
+    if (use_ws) {
+        long blocks = (((long)M * N >> 2) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, split_k, (long)M * N, N, C, ldc, accumulate);
+        QT_CHECK_LAUNCH("qt_splitk_reduce");
+    }
     return (c_amax && split_k > 1) ? 2 : QT_OK;
 }
 
@@ -1166,9 +1199,10 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
                           const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
                           float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
-                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax) {
+                          float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
+                          float* ws, long ws_floats) {
     return plane_gemm("qt_gemm_ps", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
-                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, c_amax);
+                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, c_amax, ws, ws_floats);
 }
 
 // BASELINE configs[4]: C[M,N] = epilogue(alpha/(s_a s_b) * A B^T) with A [M rows][K] and B [N rows][K] (nn.Linear weight) given as

@@ -390,6 +390,19 @@ def reshape(x: Tensor, shape) -> Tensor:
     return _ReshapeFn.apply(x, tuple(shape)) if x.requires_grad and torch.is_grad_enabled() else x.reshape(shape)
 
 
+_splitk_ws: Optional[Tensor] = None
+SPLITK_WS_FLOATS = 32 << 20          # 128 MiB: split x M x N of every dW product of the path (2304 x 768 at split 14, 3072 x 768 at split 7)
+
+
+def _splitk_workspace(device) -> Tensor:
+    """One workspace per process for the K-split slabs of the dW GEMMs (include/qatiger.h qt_gemm_ps `ws`): launches are stream-ordered,
+    so consecutive GEMMs reuse it; allocated on first use (outside any graph capture: the warm-up steps come first)."""
+    global _splitk_ws
+    if _splitk_ws is None or _splitk_ws.device != torch.device(device):
+        _splitk_ws = torch.empty(SPLITK_WS_FLOATS, device=device, dtype=torch.float32)
+    return _splitk_ws
+
+
 def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: bool = False, out: Optional[Tensor] = None,
             bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: int = 0,
             mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
@@ -411,12 +424,13 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
         add = as2d(add)
     if mask_src is not None:
         mask_src = as2d(mask_src)
+    ws = _splitk_workspace(out.device) if (a_kslow and b_kslow) else None      # dW products: K splits meet in a workspace, not through atomics
     rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(a_kslow), int(b_kslow), 'ps'), lambda: _lib.load().qt_gemm_ps(
         _stream(), int(a_kslow), int(b_kslow), M, N, K, float(alpha),
         _ptr(a.data), 4 * a.data.stride(0), _ptr(a.amax), _ptr(b.data), 4 * b.data.stride(0), _ptr(b.amax),       # (a column block of an image is an image)
         _ptr(out), _ld(out), _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
-        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), _ptr(c_amax)))
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), _ptr(c_amax), _ptr(ws), ws.numel() if ws is not None else 0))
     if rc == -4:
         if timer is not None:
             timer.records.pop()

@@ -97,6 +97,27 @@ def test_gemm_ps_split_k_and_epilogues(ops):
     assert torch.equal(d1 == 0, d2 == 0) and rel(d1, d2) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(768, 768, 30720), (2304, 768, 9984), (512, 256, 4096)])
+def test_gemm_ps_split_k_through_workspace(ops, M, N, K, monkeypatch):
+    """dW-shaped products (both operands K-slow, small output over a long K): the K splits store their partial tiles into slabs of a
+    workspace and one pass sums them in a fixed order (qt_gemm_ps `ws`) — fp32-level against fp64, bit-identical from run to run,
+    `accumulate` adds to what C holds, and equal (to summation order) to the atomics route (QT_PS_ATOMIC=1)."""
+    a, b = rnd(K, M, seed=5, scale=1e-3), rnd(K, N, seed=6)
+    am = ops.amax_of(a.to(DEV), keep=True)
+    ia, ib = ops.split_image(a.to(DEV), amax=am), ops.split_image(b.to(DEV))
+    ref = a.double().t() @ b.double()
+    o1 = ops.gemm_ps(ia, ib, a_kslow=True, b_kslow=True)
+    o2 = ops.gemm_ps(ia, ib, a_kslow=True, b_kslow=True)
+    assert rel(o1, ref) < 2e-6 and torch.equal(o1, o2)
+    c0 = rnd(M, N, seed=7, scale=1e-2)
+    c = c0.clone().to(DEV)
+    ops.gemm_ps(ia, ib, a_kslow=True, b_kslow=True, out=c, accumulate=True)
+    assert rel(c, c0.double() + ref) < 2e-6
+    monkeypatch.setenv('QT_PS_ATOMIC', '1')
+    o3 = ops.gemm_ps(ia, ib, a_kslow=True, b_kslow=True)
+    assert rel(o3, ref) < 2e-6 and rel(o1, o3) < 1e-6
+
+
 @pytest.mark.parametrize('wmt', [2, 3, 4])
 def test_gemm_ps_both_tile_heights(ops, wmt, monkeypatch):
     """The launcher picks the 192-row (WMT 3) or the 256-row (WMT 4) tile by its cost model; QT_PS_WMT pins it.  Row-form A
