@@ -73,7 +73,10 @@ int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N
                                       range before its split and the result is scaled back: backward GEMMs pass max|dY| here */,
                const float* b_amax /* the same for B */,
                float* c_amax /* nullable: max|C| record of the values written — the next layer's max|dY| for free.  A launch that had to split K
-                                 (partial sums meet in atomics) does not fill it and returns 2 instead of 0: measure C with qt_amax_f32 then */);
+                                 does not fill it and returns 2 instead of 0: measure C with qt_amax_f32 then */,
+               float* ws /* nullable: caller-owned workspace; when the launch splits K (one problem) and split * M * N floats fit, the splits
+                            store their partial tiles there and a second launch sums them into C in a fixed order (no atomics, no zeroing) */,
+               long ws_floats);
 
 /* softmax(q k^T * scale) -> dropout -> · v for every (item, head).
  * Replaces the core of nn.MultiheadAttention (torch F.multi_head_attention_forward

@@ -1089,6 +1089,14 @@ __global__ __launch_bounds__(256) void qt_splitk_reduce_kernel(const float* __re
     }
 }
 
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate) {     // (also used by gemm_split.hip)
+    long blocks = (((long)M * N >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate);
+    QT_CHECK_LAUNCH("qt_splitk_reduce");
+    return QT_OK;
+}
+
 // Shared launcher.  fmt 0: fp16 (hi | lo) lines, K step 32;  fmt 1: e4m3 lines, K step 128, row-form operands only.
 static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
                       const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
@@ -1182,12 +1190,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);
-    if (use_ws) {
-        long blocks = (((long)M * N >> 2) + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws, split_k, (long)M * N, N, C, ldc, accumulate);
-        QT_CHECK_LAUNCH("qt_splitk_reduce");
-    }
+    if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate); if (rc) return rc; }
     return (c_amax && split_k > 1) ? 2 : QT_OK;
 }
 

@@ -59,6 +59,8 @@ struct GemmArgs {          // identical to gemm.hip
     const float* a_amax;      // nullable: device max|A|; A is multiplied by the power of two that puts it in fp16's normal range before its split
     const float* b_amax;      // the same for B
     float* c_amax;            // nullable: max|C| record (64 floats) of the values this launch writes (non-split-K launches): the next layer's dY scale (products whose gradient operand is B: dV = P^T dO, dW_k = q^T dU)
+    float* ws; long ws_stride; // split-K through a workspace (batch == 1): K split z stores its partial tile at ws + z * ws_stride (row pitch N) with plain
+                              // stores and qt_splitk_reduce sums the slabs into C in a fixed order — no atomics, no zeroing launch, reproducible bits
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
         const int em0 = m0, en0 = n0;
         float* const eC = p.C;
         const bool first_split = (ksplit == 0);
+        float* const ws_slab = p.ws ? p.ws + (long)ksplit * p.ws_stride : nullptr;
         if (do_csum && m0 + (tid % BM) < p.M) atomicAdd(p.a_colsum + m0 + (tid % BM), csum);
         w += G;
         const bool more = w < total;
@@ -440,7 +443,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN >= 8) ? 2 : 2) void qt_g
                             if (ncol0 + j * 32 < p.N) {
                                 float v = alpha_s * acc[i][j][e] + bias_v[j];
                                 if (has_add) v += addv[e8][j];
-                                if (atomic) { atomicAdd(crow + j * 32, v); return; }
+                                if (atomic) {
+                                    if (ws_slab) ws_slab[(long)m * p.N + ncol0 + j * 32] = v;
+                                    else atomicAdd(crow + j * 32, v);
+                                    return;
+                                }
                                 if (act == 1) v = qt_relu(v);
                                 else if (act == 2) v = v / (1.0f + __expf(-1.702f * v));
                                 if constexpr (full) {
@@ -524,12 +531,15 @@ int qt_gemm_sk(void* stream, int half_type, int transA, int transB, int M, int N
                float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
                int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax, float* c_amax);
 
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate);   // gemm_plane.hip
+
 extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N, int K, float alpha,
                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                           const float* bias, const float* add_src, long ld_add, int relu,
                           const float* mask_src, long ld_mask, float mask_scale,
                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
-                          int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax, float* c_amax) {
+                          int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax, float* c_amax,
+                          float* ws, long ws_floats) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "qt_gemm_x3: bad problem");
     QT_CHECK_ARG(!a_colsum || transA, "qt_gemm_x3: a_colsum needs transA (A given as [K,M])");
     if (batch < 1) batch = 1;
@@ -609,7 +619,12 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
     kps = ((kps + SBK - 1) / SBK) * SBK;
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
-    if (split_k > 1 && !accumulate) {
+    // K splits meet in the caller's workspace when it holds the slabs (one problem, rows of C 16-byte aligned): plain stores + one
+    // summing pass instead of a zeroing launch + fp32 atomics (768x768x3840 at split 14: 8.3 M atomics = 30 of the launch's 56 us)
+    const bool use_ws = split_k > 1 && batch == 1 && ws && qt_aligned16(ws) && (long)split_k * M * N <= ws_floats &&
+                        N % 4 == 0 && ldc % 4 == 0 && qt_aligned16(C) && !getenv("QT_PS_ATOMIC");
+    a.ws = use_ws ? ws : nullptr; a.ws_stride = (long)M * N;
+    if (split_k > 1 && !accumulate && !use_ws) {
         for (int z = 0; z < batch; ++z) {
             hipError_t e = qt_zero_2d(C + (long)z * c_bs, ldc, M, N, st);
             if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_x3: memset: %s", hipGetErrorString(e));
@@ -638,6 +653,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         else qt_x3_small_3(a, transA, transB, grid, st);
     }
     QT_CHECK_LAUNCH("qt_gemm_x3");
+    if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate); if (rc) return rc; }
     return cmax_skipped ? 2 : QT_OK;
 }
 #endif  // QT_X3_PART == 0

@@ -193,8 +193,10 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
             float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k))
     btail = (int(nb), int(a_bs), int(b_bs), int(c_bs))
     if mode != 'fp32':
+        ws = _splitk_workspace(a.device) if nb == 1 else None          # K splits of one problem meet in the workspace, not through atomics
         rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), mode) + ((nb,) if nb > 1 else ()),
-                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail, _ptr(a_amax), _ptr(b_amax), _ptr(c_amax)))
+                     lambda: _lib.load().qt_gemm_x3(_stream(), _HALF_TYPE[mode], *tail, _ptr(a_colsum), *btail, _ptr(a_amax), _ptr(b_amax), _ptr(c_amax),
+                                                    _ptr(ws), ws.numel() if ws is not None else 0))
         if rc == 0:
             return out
         if rc == 2:                                    # done, but a split-K launch could not measure max|C|: one explicit pass

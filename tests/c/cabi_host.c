@@ -37,7 +37,7 @@ int main(void) {
     for (int pass = 0; pass < 2; ++pass) {
         int rc = pass == 0
             ? qt_gemm_f32(NULL, 0, 1, M, N, K, 1.0f, dx, K, dw, K, dy, N, db, NULL, 0, 1, NULL, 0, 1.0f, 0.0f, 0ull, 0, 0, 1, 0, 0, 0)
-            : qt_gemm_x3(NULL, 0, 0, 1, M, N, K, 1.0f, dx, K, dw, K, dy, N, db, NULL, 0, 1, NULL, 0, 1.0f, 0.0f, 0ull, 0, 0, NULL, 1, 0, 0, 0, NULL, NULL, NULL);
+            : qt_gemm_x3(NULL, 0, 0, 1, M, N, K, 1.0f, dx, K, dw, K, dy, N, db, NULL, 0, 1, NULL, 0, 1.0f, 0.0f, 0ull, 0, 0, NULL, 1, 0, 0, 0, NULL, NULL, NULL, NULL, 0);
         if (rc != 0) { fprintf(stderr, "gemm pass %d: rc=%d %s\n", pass, rc, qt_last_error()); return 3; }
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(y, dy, sizeof(float) * M * N, hipMemcpyDeviceToHost));

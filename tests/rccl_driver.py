@@ -160,4 +160,8 @@ def main(rank: int, world: int, port: int) -> int:
 
 
 if __name__ == '__main__':
-    sys.exit(main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])))
+    code = main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+    sys.stdout.flush(); sys.stderr.flush()
+    # (leave without the interpreter's teardown: after destroy_process_group RCCL's watchdog thread sometimes throws while the runtime
+    # unloads — SIGABRT after every check had passed and the report had been printed, about one run in five on the test box)
+    os._exit(code)
