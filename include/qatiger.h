@@ -54,6 +54,14 @@ int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float
                 const float* mask_src, long ld_mask, float mask_scale,
                 float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
                 int batch, long a_bs, long b_bs, long c_bs);
+/* The same with a caller-owned split-K workspace (as qt_gemm_x3's `ws`): K splits of one problem store their partial tiles there and a
+ * second launch sums them in a fixed order — no atomics, no zeroing launch, reproducible bits. */
+int qt_gemm_f32_ws(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                const float* bias, const float* add_src, long ld_add, int relu /* 0 none, 1 ReLU, 2 QuickGELU (clip_base.py:166-168) */,
+                const float* mask_src, long ld_mask, float mask_scale,
+                float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
+                int batch, long a_bs, long b_bs, long c_bs, float* ws, long ws_floats);
 
 /* Same contract as qt_gemm_f32, computed with three 16-bit MFMAs per product on operands split
  * on the fly into hi+lo parts (half_type 0: fp16 parts, ~fp32-accurate, operands must be inside

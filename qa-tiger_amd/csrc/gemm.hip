@@ -25,6 +25,7 @@
 // group, h: lane half, s: element) for BOTH operands, which is all that a dot
 // product needs.
 #include "qt_common.h"
+#include <stdlib.h>
 
 #define BK 16
 #define LDK (BK + 4)   // padded row of a K-contiguous tile (floats); 80 B keeps 16-B alignment
@@ -45,6 +46,7 @@ struct GemmArgs {
     int k_per_split;                   // multiple of BK
     int tiles_n;
     long a_bs, b_bs, c_bs;             // strides between the gridDim.z problems of a batched launch
+    float* ws; long ws_stride;         // split-K through a workspace (one problem): split z stores its partial tile at ws + z * ws_stride (row pitch N)
 };
 
 template <int TM, int TN, bool TA, bool TB, int VEC>
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(256) void qt_gemm_f32_kernel(GemmArgs p) {
                 float* dst = p.C + (long)m * p.ldc + n;
                 if (p.split_k > 1) {
                     if (p.add_src && first_split) v += p.add_src[(long)m * p.ld_add + n];
-                    atomicAdd(dst, v);
+                    if (p.ws) p.ws[(long)blockIdx.y * p.ws_stride + (long)m * p.N + n] = v;     // summed by qt_splitk_reduce in a fixed order
+                    else atomicAdd(dst, v);
                     continue;
                 }
                 if (p.add_src) v += p.add_src[(long)m * p.ld_add + n];
@@ -250,12 +253,14 @@ static void launch_cfg(const GemmArgs& a, int transA, int transB, dim3 grid, hip
     else                         hipLaunchKernelGGL((qt_gemm_f32_kernel<TM, TN, true, true, VEC>), grid, dim3(256), 0, st, a);
 }
 
-extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate);   // gemm_plane.hip
+
+extern "C" int qt_gemm_f32_ws(void* stream, int transA, int transB, int M, int N, int K, float alpha,
                            const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                            const float* bias, const float* add_src, long ld_add, int relu,
                            const float* mask_src, long ld_mask, float mask_scale,
                            float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
-                           int batch, long a_bs, long b_bs, long c_bs) {
+                           int batch, long a_bs, long b_bs, long c_bs, float* ws, long ws_floats) {
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0, "qt_gemm_f32: empty problem M=%d N=%d K=%d", M, N, K);
     QT_CHECK_ARG(A && B && C, "qt_gemm_f32: null operand");
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "qt_gemm_f32: drop_p=%f", drop_p);
@@ -298,7 +303,11 @@ extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, i
     kps = ((kps + BK - 1) / BK) * BK;
     split_k = (K + kps - 1) / kps;
     a.split_k = split_k; a.k_per_split = kps;
-    if (split_k > 1 && !accumulate) {   // partial sums are atomically added into a zeroed C
+    // K splits of one problem meet in the caller's workspace when it holds the slabs (plain stores + one summing pass, fixed order);
+    // otherwise through atomics into a zeroed C
+    const bool use_ws = split_k > 1 && batch == 1 && ws && (long)split_k * M * N <= ws_floats && !getenv("QT_PS_ATOMIC");
+    a.ws = use_ws ? ws : nullptr; a.ws_stride = (long)M * N;
+    if (split_k > 1 && !accumulate && !use_ws) {   // partial sums are atomically added into a zeroed C
         for (int z = 0; z < batch; ++z) {
             hipError_t e = qt_zero_2d(C + (long)z * c_bs, ldc, M, N, st);
             if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_gemm_f32: memset: %s", hipGetErrorString(e));
@@ -309,5 +318,16 @@ extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, i
     if (small) { if (vec == 4) launch_cfg<1, 1, 4>(a, transA, transB, grid, st); else launch_cfg<1, 1, 1>(a, transA, transB, grid, st); }
     else       { if (vec == 4) launch_cfg<2, 2, 4>(a, transA, transB, grid, st); else launch_cfg<2, 2, 1>(a, transA, transB, grid, st); }
     QT_CHECK_LAUNCH("qt_gemm_f32");
+    if (use_ws) return qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate);
     return QT_OK;
+}
+
+extern "C" int qt_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, float alpha,
+                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                           const float* bias, const float* add_src, long ld_add, int relu,
+                           const float* mask_src, long ld_mask, float mask_scale,
+                           float drop_p, unsigned long long drop_seed, int accumulate, int split_k,
+                           int batch, long a_bs, long b_bs, long c_bs) {
+    return qt_gemm_f32_ws(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale,
+                          drop_p, drop_seed, accumulate, split_k, batch, a_bs, b_bs, c_bs, nullptr, 0);
 }

@@ -1089,10 +1089,21 @@ __global__ __launch_bounds__(256) void qt_splitk_reduce_kernel(const float* __re
     }
 }
 
-int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate) {     // (also used by gemm_split.hip)
-    long blocks = (((long)M * N >> 2) + 255) / 256;
+__global__ __launch_bounds__(256) void qt_splitk_reduce1_kernel(const float* __restrict__ ws, int split, long mn, int N, float* __restrict__ C, long ldc, int accumulate) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < mn; e += (long)gridDim.x * 256) {     // any N, any alignment
+        float acc = ws[e];
+        for (int z = 1; z < split; ++z) acc += ws[(long)z * mn + e];
+        const long m = e / N;
+        float* dst = C + m * ldc + (e - m * N);
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate) {     // (also used by gemm_split.hip, gemm.hip)
+    const bool vec = N % 4 == 0 && ldc % 4 == 0 && qt_aligned16(C) && qt_aligned16(ws);
+    long blocks = (((long)M * N >> (vec ? 2 : 0)) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate);
+    if (!vec) hipLaunchKernelGGL(qt_splitk_reduce1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate);
+    else hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate);
     QT_CHECK_LAUNCH("qt_splitk_reduce");
     return QT_OK;
 }

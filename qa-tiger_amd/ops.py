@@ -208,12 +208,13 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
         if timer is not None:
             timer.records.pop()
 
-    rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), 'fp32') + ((nb,) if nb > 1 else ()), lambda: _lib.load().qt_gemm_f32(
+    ws = _splitk_workspace(a.device) if nb == 1 else None
+    rc = _launch('gemm', 2.0 * M * N * K * nb, (M, N, K, int(trans_a), int(trans_b), 'fp32') + ((nb,) if nb > 1 else ()), lambda: _lib.load().qt_gemm_f32_ws(
         _stream(), int(trans_a), int(trans_b), M, N, K, float(alpha),
         _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out),
         _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
         _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
-        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), *btail))
+        float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), *btail, _ptr(ws), ws.numel() if ws is not None else 0))
     _lib.check(rc, 'qt_gemm_f32')
     if a_colsum is not None:                           # the fp32 kernel has no fused column sum
         _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), 0), 'qt_colsum')
