@@ -653,7 +653,11 @@ class GradSink:
 def share_grad(x: Tensor) -> Tensor:
     """Mark an activation whose gradient contributions should meet in one buffer (see GradSink); returns x."""
     if x.requires_grad and torch.is_grad_enabled():
-        x._qt_sink = GradSink()
+        sink = x._qt_sink = GradSink()
+
+        def done(_g, sink=sink):                     # runs when x's gradient is complete (all consumers have run), before its producer's backward:
+            sink.buf = sink.holder = None            # a second backward over a retained graph starts from an empty sink, and the buffer is not kept alive
+        x.register_hook(done)
     return x
 
 

@@ -708,3 +708,20 @@ def test_graphed_forward_follows_weight_changes(qt, synth):
     assert relerr(got, eager) < 1e-5
     torch.zeros(64 << 20, device=DEV).fill_(7.0)                       # recycle whatever the eager pass freed
     assert relerr(gf(batch)['out'], eager) < 1e-5
+
+
+def test_gradient_sinks_survive_a_second_backward_over_a_retained_graph(qt, synth):
+    """`ops.share_grad` tensors (the stacked AVQ input, norm1's output, the projected question) collect their consumers' gradients in
+    one buffer that the first consumer hands to autograd.  The buffer must be forgotten once the gradient is complete: a second
+    backward over the same (retained) graph has to produce the same gradients as the first, not accumulate into the old buffer."""
+    cfg = synth.PathConfig(**{**synth.CONFIG_2.asdict(), 'B': 8})
+    model = build(qt, synth, cfg, 713)
+    batch = to_dev(synth.make_inputs(cfg, 713))
+    loss = qt.CrossEntropyLoss()(model(batch)['out'], batch['label'])
+    grads = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        loss.backward(retain_graph=True)
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    for n, g in grads[0].items():
+        assert l2rel(grads[1][n].cpu().numpy(), g.cpu().numpy()) < 1e-5, n
