@@ -248,6 +248,15 @@ int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, floa
                const float* mask_src, long ld_mask, float mask_scale,
                float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
                float* ws, long ws_floats);
+/* qt_gemm_ps that ALSO writes C as an unscaled split image (row pitch ld_img_bytes, a multiple of 128): the operand of the Linear layer
+ * that consumes C, produced by the epilogue that holds the values in registers instead of by a qt_split_f16 pass over C.  Returns 3
+ * (C written, image NOT written) when the launch cannot do it (a K split, unaligned rows): the caller then splits C as usual. */
+int qt_gemm_ps_img(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                   const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                   float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+                   const float* mask_src, long ld_mask, float mask_scale,
+                   float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
+                   void* c_img, long ld_img_bytes);
 
 /* ---- BASELINE configs[4] ("fp8 MFMA on projection GEMMs"): e4m3 operand images and the GEMM on
  * v_mfma_scale_f32_32x32x64_f8f6f4 (fp32 accumulate, fp32 epilogue).  Outside the 1e-3 parity gate by construction: judged by

@@ -57,6 +57,8 @@ struct PlaneArgs {
     float alpha;
     const float* a_amax; const float* b_amax;   // nullable: max|x| the operand's image was scaled by (qt_split_f16)
     float* c_amax;                              // nullable: record that receives max|C| as written (never with split-K atomics)
+    char* c_img; long ld_img;                   // nullable: ALSO write C as a split image (unscaled (hi | lo) fp16 lines, row pitch ld_img bytes): the operand of the
+                                                // Linear layer that consumes C, without a split pass (16x16x32 form, C^T orientation, no K split)
     const float* bias;
     const float* add_src; long ld_add;
     int relu;
@@ -702,6 +704,15 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                     if (m < p.M && n < p.N) {
                         cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         *reinterpret_cast<float4*>(Cw + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (p.c_img) {                                  // the same four columns as fp16 parts: 8 bytes of hi, 8 bytes of lo
+                            const f32x2 x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
+                            const f16x2 h01 = __builtin_convertvector(x01, f16x2), h23 = __builtin_convertvector(x23, f16x2);
+                            const f16x2 l01 = __builtin_convertvector(x01 - __builtin_convertvector(h01, f32x2), f16x2);
+                            const f16x2 l23 = __builtin_convertvector(x23 - __builtin_convertvector(h23, f32x2), f16x2);
+                            char* line = p.c_img + (long)m * p.ld_img + (long)(n >> 5) * 128 + (n & 31) * 2;
+                            *reinterpret_cast<uint2*>(line) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                            *reinterpret_cast<uint2*>(line + 64) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+                        }
                     }
                 });
             });
@@ -1114,7 +1125,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
                       float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                       const float* mask_src, long ld_mask, float mask_scale,
                       float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
-                      float* ws = nullptr, long ws_floats = 0) {
+                      float* ws = nullptr, long ws_floats = 0, void* c_img = nullptr, long ld_img = 0) {
     const int KS = fmt == 1 ? 128 : PBK;
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "%s: bad problem", who);
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "%s: drop_p=%f", who, drop_p);
@@ -1197,11 +1208,15 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     // the same images, tools/ab_mfma_shape.py); QT_PS_MF=0 selects the 32x32x16 form (A/B runs; read per call)
     int mf = 1;
     { const char* e = getenv("QT_PS_MF"); if (e) mf = atoi(e); }
+    // the image of C rides on the 16x16x32 C^T epilogue of an unsplit launch; otherwise it is not written (return 3: the caller splits C)
+    const bool img_ok = c_img && fmt == 0 && mf && swap && split_k == 1 && N % 32 == 0 && ld_img % 128 == 0 && qt_aligned16(c_img);
+    a.c_img = img_ok ? (char*)c_img : nullptr; a.ld_img = ld_img;
     if (fmt == 1) qt_ps_launch_fp8(a, 0, 0, swap, 4, grid, st);
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);
     if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate); if (rc) return rc; }
+    if (c_img && !img_ok) return 3;
     return (c_amax && split_k > 1) ? 2 : QT_OK;
 }
 
@@ -1217,6 +1232,20 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
                           float* ws, long ws_floats) {
     return plane_gemm("qt_gemm_ps", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
                       bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, c_amax, ws, ws_floats);
+}
+
+// qt_gemm_ps that ALSO writes C as an unscaled split image (c_img, row pitch ld_img_bytes: the operand of the next Linear layer, made by
+// the epilogue that has the values in registers instead of by a split pass over C).  Returns 3 (C written, image NOT written) when the
+// launch cannot do it (K split, unaligned rows, the 32x32x16 form): the caller then splits C as usual.
+extern "C" int qt_gemm_ps_img(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                              const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                              float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
+                              const float* mask_src, long ld_mask, float mask_scale,
+                              float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
+                              void* c_img, long ld_img_bytes) {
+    return plane_gemm("qt_gemm_ps_img", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
+                      bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, c_amax, nullptr, 0,
+                      c_img, ld_img_bytes);
 }
 
 // BASELINE configs[4]: C[M,N] = epilogue(alpha/(s_a s_b) * A B^T) with A [M rows][K] and B [N rows][K] (nn.Linear weight) given as

@@ -389,8 +389,18 @@ class _ReshapeFn(torch.autograd.Function):
         return g2, None
 
 
+def _carry_image(src: Tensor, dst: Tensor) -> None:
+    """A producer-written operand image (gemm_ps emit_image) belongs to the ROWS, whatever the leading dimensions are folded into."""
+    cached = getattr(src, '_qt_img', None)
+    if cached is not None and dst is not src and cached[0] == (src._version, src.data_ptr(), pass_epoch) and not getattr(src, '_qt_is_image', False) \
+            and src.is_contiguous() and dst.is_contiguous() and dst.shape[-1] == src.shape[-1] and dst.data_ptr() == src.data_ptr():
+        dst._qt_img = ((dst._version, dst.data_ptr(), pass_epoch), cached[1])
+
+
 def reshape(x: Tensor, shape) -> Tensor:
-    return _ReshapeFn.apply(x, tuple(shape)) if x.requires_grad and torch.is_grad_enabled() else x.reshape(shape)
+    out = _ReshapeFn.apply(x, tuple(shape)) if x.requires_grad and torch.is_grad_enabled() else x.reshape(shape)
+    _carry_image(x, out)
+    return out
 
 
 _splitk_ws: Optional[Tensor] = None
@@ -409,10 +419,13 @@ def _splitk_workspace(device) -> Tensor:
 def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: bool = False, out: Optional[Tensor] = None,
             bias: Optional[Tensor] = None, add: Optional[Tensor] = None, relu: int = 0,
             mask_src: Optional[Tensor] = None, mask_scale: float = 1.0, drop_p: float = 0.0, seed: int = 0,
-            accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, c_amax: Optional[Tensor] = None) -> Optional[Tensor]:
+            accumulate: bool = False, alpha: float = 1.0, split_k: int = 0, c_amax: Optional[Tensor] = None,
+            emit_image: bool = False) -> Optional[Tensor]:
     """out[M,N] = epilogue(alpha * op(a) @ op(b)) on split images; returns None (out untouched) when the shape does not fit
     the kernel (the caller then uses `gemm` on the fp32 tensors).
-    c_amax: a zeroed max|x| record; when the launch could fill it (no split-K atomics) the returned tensor carries it as `_qt_amax`."""
+    c_amax: a zeroed max|x| record; when the launch could fill it (no split-K atomics) the returned tensor carries it as `_qt_amax`.
+    emit_image: the epilogue also writes `out` as an unscaled split image (qt_gemm_ps_img); the returned tensor then carries it as
+    `_qt_img`, where the Linear layer that consumes it finds it (input_image) instead of running a split pass."""
     M, K = (a.cols, a.rows) if a_kslow else (a.rows, a.cols)
     N, Kb = (b.cols, b.rows) if b_kslow else (b.rows, b.cols)
     if K != Kb:
@@ -427,6 +440,24 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
         add = as2d(add)
     if mask_src is not None:
         mask_src = as2d(mask_src)
+    if emit_image and N % 32 == 0 and not (a_kslow or b_kslow) and split_k in (0, 1) and not accumulate:
+        img = torch.empty((M, N), device=out.device, dtype=torch.float32)
+        rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, 0, 0, 'ps'), lambda: _lib.load().qt_gemm_ps_img(
+            _stream(), 0, 0, M, N, K, float(alpha),
+            _ptr(a.data), 4 * a.data.stride(0), _ptr(a.amax), _ptr(b.data), 4 * b.data.stride(0), _ptr(b.amax),
+            _ptr(out), _ld(out), _ptr(bias), _ptr(add), _ld(add) if add is not None else 0, int(relu),
+            _ptr(mask_src), _ld(mask_src) if mask_src is not None else 0, float(mask_scale),
+            float(drop_p), C.c_ulonglong(seed), 0, 1, _ptr(c_amax), _ptr(img), 4 * N))
+        if rc == -4:
+            if timer is not None:
+                timer.records.pop()
+            return None
+        if rc not in (2, 3):
+            _lib.check(rc, 'qt_gemm_ps_img')
+            if c_amax is not None:
+                tag_amax(out, c_amax)
+            out._qt_img = ((out._version, out.data_ptr(), pass_epoch), SplitImage(img, M, N, None))
+        return out
     ws = _splitk_workspace(out.device) if (a_kslow and b_kslow) else None      # dW products: K splits meet in a workspace, not through atomics
     rc = _launch('gemm', 2.0 * M * N * K, (M, N, K, int(a_kslow), int(b_kslow), 'ps'), lambda: _lib.load().qt_gemm_ps(
         _stream(), int(a_kslow), int(b_kslow), M, N, K, float(alpha),
@@ -791,6 +822,7 @@ def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     return img
 
 
+emit_images = _os.environ.get('QT_EMIT_IMAGE', '1') != '0'       # GEMM epilogues write the next Linear layer's operand image (A/B switch)
 robust_range = _os.environ.get('QT_ROBUST_RANGE', '0') != '0'   # also measure max|x| of every Linear INPUT (one extra read of it per layer)
 
 
@@ -850,7 +882,7 @@ def grad_amax(dy: Tensor, g2: Optional[Tensor] = None) -> Optional[Tensor]:
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool, drop_p: float, seed: int,
-                residual: Optional[Tensor], grad_premasked: bool, link: Optional[GradLink] = None):
+                residual: Optional[Tensor], grad_premasked: bool, link: Optional[GradLink] = None, emit_image: bool = False):
         ctx.link = link
         ctx.sink = getattr(x, '_qt_sink', None) if link is None else None
         shape = x.shape
@@ -872,7 +904,8 @@ class LinearFn(torch.autograd.Function):
             wimg = weight_image(weight)
             if wimg is not None:
                 ximg = input_image(x, x2)
-                y = gemm_ps(ximg, wimg, bias=bias, add=residual, relu=int(relu), drop_p=drop_p, seed=seed)
+                y = gemm_ps(ximg, wimg, bias=bias, add=residual, relu=int(relu), drop_p=drop_p, seed=seed,
+                            emit_image=emit_image and emit_images and not robust_range and x2.shape[0] >= plane_dw_min_rows)
         if getattr(x, '_qt_is_image', False) and (y is None or x2.shape[0] < plane_dw_min_rows):
             raise _lib.QTError('a tensor that holds a split image (attention output written for the pre-split GEMM) reached a Linear layer '
                                'that reads fp32 rows')
@@ -895,7 +928,9 @@ class LinearFn(torch.autograd.Function):
         ctx.wimg = wimg                             # the weight's image (weights do not change between forward and backward)
         ctx.params = (weight, bias)                 # the Parameter objects themselves (saved tensors come back as new objects)
         ctx.cfg = (relu, drop_p, seed, bias is not None, residual is not None, grad_premasked, shape)
-        return y.reshape(*shape[:-1], weight.shape[0])
+        out = y.reshape(*shape[:-1], weight.shape[0])
+        _carry_image(y, out)
+        return out
 
     @staticmethod
     def backward(ctx, dy: Tensor):
@@ -1006,15 +1041,17 @@ class LinearFn(torch.autograd.Function):
             if link is not None and g.dim() == 2 and g.stride(1) == 1:
                 link.buf = g                            # same memory as dres: the linked first layer adds its dX here
                 link.res = dres
-        return dx, dw, db, None, None, None, dres, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False, drop_p: float = 0.0,
            seed: int = 0, residual: Optional[Tensor] = None, grad_premasked: bool = False,
-           link: Optional[GradLink] = None) -> Tensor:
+           link: Optional[GradLink] = None, emit_image: bool = False) -> Tensor:
+    """emit_image: the result feeds another large Linear layer — let the GEMM epilogue write its operand image as well (the fp32 result is
+    still written: residual adds, attention and LayerNorm kernels read it), so that layer needs no split pass."""
     if precision['fwd'] == 'fp8' and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         raise _lib.QTError("precision 'fp8' (BASELINE configs[4]) is a forward-only mode: run it under torch.no_grad()")
-    return LinearFn.apply(x, weight, bias, relu, drop_p, seed, residual, grad_premasked, link)
+    return LinearFn.apply(x, weight, bias, relu, drop_p, seed, residual, grad_premasked, link, emit_image)
 
 
 # --------------------------------------------------------------------------- #

@@ -68,7 +68,9 @@ class Projection(nn.Module):
         self.proj = nn.Linear(inp_dim, d_model)
 
     def forward(self, inp: Tensor) -> Tensor:
-        return ops.linear(inp, self.proj.weight, self.proj.bias)
+        # `emit_image` (set by QA_TIGER on patch_proj): the result's first consumer is a large Linear layer (PatchSelecter's packed
+        # in-projection), so the GEMM epilogue writes that layer's operand image along with the fp32 rows
+        return ops.linear(inp, self.proj.weight, self.proj.bias, emit_image=getattr(self, 'emit_image', False))
 
 
 class AVQCrossAttn(nn.Module):
@@ -118,7 +120,7 @@ class AVQCrossAttn(nn.Module):
         a_q = ops.linear(o_q, self.qst_attn.out_proj.weight, self.qst_attn.out_proj.bias)
         x = ops.share_grad(ops.add_layer_norm([x, a_s, a_c, a_q], self.norm1.weight, self.norm1.bias,
                                               drops=[False, True, True, True], drop_p=p))      # feeds linear1 and the residual of norm2
-        h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p, seed=nxt())
+        h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p, seed=nxt(), emit_image=True)    # h feeds linear2
         f = ops.linear(h, self.linear2.weight, self.linear2.bias)
         x = ops.add_layer_norm([x, f], self.norm2.weight, self.norm2.bias, drops=[False, True], drop_p=p)
         if visualize:
@@ -303,8 +305,8 @@ class PatchSelecter(nn.Module):
         else:
             kv = ops.linear(psa, *_mha_proj(self.crs_attn, 'kv'))
             o_c = ops.attention(qc, kv, AttnSpec(BT, BT, 0, H, 2, P, D, 0, 0, D, q_is=1, q_rs=BT, o_rows=2 * BT), p, nxt())
-        a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias, drop_p=p, seed=nxt())
-        m = ops.linear(ops.linear(a_c, self.mlp[0].weight, self.mlp[0].bias, relu=True), self.mlp[2].weight, self.mlp[2].bias)
+        a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias, drop_p=p, seed=nxt(), emit_image=True)
+        m = ops.linear(ops.linear(a_c, self.mlp[0].weight, self.mlp[0].bias, relu=True, emit_image=True), self.mlp[2].weight, self.mlp[2].bias)
         v_rel, a_rel = m[:BT], m[BT:]
         # return order is [audio, video] (modules.py:713-716, quirk Q5)
         return [ops.add_layer_norm([a_rel], self.anorm.weight, self.anorm.bias).reshape(B, T, D),

@@ -42,6 +42,7 @@ class QA_TIGER(nn.Module):
         self.audio_proj = Projection(audio_dim, d_model)
         self.video_proj = Projection(video_dim, d_model)
         self.patch_proj = Projection(patch_dim, d_model)
+        self.patch_proj.emit_image = True            # (not a parameter or buffer: its output goes straight into PatchSelecter's in-projection GEMM)
         self.words_proj = Projection(video_dim, d_model)
         self.quest_proj = Projection(video_dim, d_model)
         self.quest_encoder = CLIP_TEncoder(encoder_type, tower=text_tower)   # text_tower: None (features are handed in) | 'vitl14' | TextConfig

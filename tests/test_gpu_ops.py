@@ -235,6 +235,29 @@ def test_attention_writes_split_image_for_its_out_projection(ops, Lq, Lk, n_item
         ops.linear(o_img, w[:64].detach(), None)
 
 
+def test_linear_emits_the_next_layers_operand_image(ops):
+    """`ops.linear(..., emit_image=True)`: the GEMM epilogue writes the split image of its result next to the fp32 rows
+    (qt_gemm_ps_img); the image is bit-identical to qt_split_f16 of the result, survives `ops.reshape` of the leading dimensions, and
+    the consuming Linear gives the same bits as on a tensor without the image (relu + dropout epilogue included)."""
+    rows, k_in, n_mid, n_out = 16384, 1024, 768, 384
+    x = rnd(32, rows // 32, k_in, seed=41)
+    w1, b1 = rnd(n_mid, k_in, seed=42, scale=0.03), rnd(n_mid, seed=43)
+    w2, b2 = rnd(n_out, n_mid, seed=44, scale=0.05), rnd(n_out, seed=45)
+    for kw in (dict(), dict(relu=True, drop_p=0.1, seed=7)):
+        ops.new_pass()
+        y = ops.linear(x, w1, b1, emit_image=True, **kw)
+        plain = ops.linear(x, w1, b1, **kw)
+        assert torch.equal(y, plain) and getattr(y, '_qt_img', None) is not None and getattr(plain, '_qt_img', None) is None
+        assert torch.equal(y._qt_img[1].data.view(torch.int32), ops.split_image(plain.reshape(rows, n_mid)).data.view(torch.int32))
+        y2 = ops.reshape(y, (rows, n_mid))
+        assert getattr(y2, '_qt_img', None) is not None and y2._qt_img[1] is y._qt_img[1]
+        timer = ops.timer = ops.KernelTimer()
+        z = ops.linear(y2, w2, b2)
+        ops.timer = None
+        assert not [r for r in timer.records if r[0] == 'split' and rows in r[2]], 'the consumer ran a split pass although its operand image was there'
+        assert torch.equal(z, ops.linear(plain.reshape(rows, n_mid), w2, b2))
+
+
 def test_linear_fn_grads(ops):
     x = rnd(5, 7, 96, seed=12).requires_grad_(True)
     w = rnd(130, 96, seed=13, scale=0.1).requires_grad_(True)
