@@ -306,50 +306,66 @@ extern "C" int qt_headbias_fwd(void* stream, const float* o, long ldo, const flo
     QT_CHECK_LAUNCH("qt_headbias_fwd");
     return QT_OK;
 }
-// one workgroup = a chunk of rows; thread t owns columns t, t + 256, ... (coalesced rows), keeps its share of d b_v in registers over the
-// chunk and folds each row's per-head sums in LDS; one atomic per column per workgroup into d b_v (zeroed by the caller or a claimed slice
-// of the pre-zeroed flat gradient buffer)
-#define QT_HB_ROWS 32
-#define QT_HB_MAXC 8            // columns per thread: E <= 2048
+// One WAVE per row at a time (4 waves per workgroup, QT_HB_ROWS rows per workgroup): a lane owns the float4 columns 4 lane + 256 c of the
+// row (coalesced 1 KiB loads), keeps its share of d b_v in registers over its rows, and the row's per-head sums are formed from the
+// lanes' partials through a per-wave LDS row (a head is 24 consecutive float4 slots when d_h = 96: no power-of-two segment) — no LDS
+// atomics (a first version let 96 threads hit one LDS address per head and row: 87 us per launch at 30720 x 768).  The four waves'
+// column sums meet in LDS, then one global atomic per column per workgroup into d b_v.
+#define QT_HB_ROWS 64
+#define QT_HB_MAXC 8            // 64-float4 chunks per row: E <= 2048
 __global__ __launch_bounds__(256) void qt_headbias_bwd_kernel(const float* __restrict__ dout, long ld, const float* __restrict__ asum, const float* __restrict__ bv,
                                                               long rows, int E, int dh, int H, float* __restrict__ dasum, float* __restrict__ dbv) {
-    __shared__ float hs[QT_HB_ROWS][33];                                        // per-row, per-head partial sums (H <= 32)
+    __shared__ float part[4][QT_HB_MAXC * 64];                                  // per wave: one partial per float4 slot of the row
+    __shared__ float4 colsum[4][QT_HB_MAXC * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long r0 = (long)blockIdx.x * QT_HB_ROWS;
     const int nr = (int)min((long)QT_HB_ROWS, rows - r0);
-    for (int i = threadIdx.x; i < QT_HB_ROWS * 33; i += 256) (&hs[0][0])[i] = 0.f;
-    __syncthreads();
-    float acc[QT_HB_MAXC], bcol[QT_HB_MAXC];
-    int hcol[QT_HB_MAXC];
+    const int nslot = E >> 2, spf = dh >> 2;                                    // float4 slots per row / per head
+    float4 acc[QT_HB_MAXC], b4[QT_HB_MAXC];
+    int hs[QT_HB_MAXC];
 #pragma unroll
     for (int c = 0; c < QT_HB_MAXC; ++c) {
-        const int e = threadIdx.x + c * 256;
-        acc[c] = 0.f; bcol[c] = e < E ? bv[e] : 0.f; hcol[c] = e < E ? e / dh : 0;
+        const int slot = lane + c * 64;
+        acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        b4[c] = slot < nslot ? *reinterpret_cast<const float4*>(bv + slot * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        hs[c] = slot < nslot ? slot / spf : 0;
     }
-    for (int r = 0; r < nr; ++r) {
+    for (int r = wave; r < nr; r += 4) {
         const float* drow = dout + (r0 + r) * ld;
         const float* arow = asum + (r0 + r) * H;
 #pragma unroll
         for (int c = 0; c < QT_HB_MAXC; ++c) {
-            const int e = threadIdx.x + c * 256;
-            if (e < E) {
-                const float d = drow[e];
-                acc[c] = fmaf(d, arow[hcol[c]], acc[c]);
-                atomicAdd(&hs[r][hcol[c]], d * bcol[c]);
+            const int slot = lane + c * 64;
+            float pv = 0.f;
+            if (slot < nslot) {
+                const float4 d = *reinterpret_cast<const float4*>(drow + slot * 4);
+                const float a = arow[hs[c]];
+                acc[c].x = fmaf(d.x, a, acc[c].x); acc[c].y = fmaf(d.y, a, acc[c].y); acc[c].z = fmaf(d.z, a, acc[c].z); acc[c].w = fmaf(d.w, a, acc[c].w);
+                pv = d.x * b4[c].x + d.y * b4[c].y + d.z * b4[c].z + d.w * b4[c].w;
             }
+            part[wave][slot] = pv;
         }
+        __builtin_amdgcn_wave_barrier();                                        // the wave's own LDS row: its LDS operations execute in order
+        if (lane < H) {
+            float s = 0.f;
+            for (int i = 0; i < spf; ++i) s += part[wave][lane * spf + i];
+            dasum[(r0 + r) * H + lane] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * H; i += 256) dasum[(r0 + i / H) * H + i % H] = hs[i / H][i % H];
 #pragma unroll
-    for (int c = 0; c < QT_HB_MAXC; ++c) {
-        const int e = threadIdx.x + c * 256;
-        if (e < E) atomicAdd(dbv + e, acc[c]);
+    for (int c = 0; c < QT_HB_MAXC; ++c) colsum[wave][lane + c * 64] = acc[c];
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < nslot; slot += 256) {
+        const float4 a = colsum[0][slot], b = colsum[1][slot], c2 = colsum[2][slot], d = colsum[3][slot];
+        atomicAdd(dbv + slot * 4 + 0, (a.x + b.x) + (c2.x + d.x)); atomicAdd(dbv + slot * 4 + 1, (a.y + b.y) + (c2.y + d.y));
+        atomicAdd(dbv + slot * 4 + 2, (a.z + b.z) + (c2.z + d.z)); atomicAdd(dbv + slot * 4 + 3, (a.w + b.w) + (c2.w + d.w));
     }
 }
 extern "C" int qt_headbias_bwd(void* stream, const float* dout, long ld, const float* asum, const float* bv, long rows, int E, int H,
                                float* dasum, float* dbv, int dbv_accumulate) {
-    QT_CHECK_ARG(dout && asum && bv && dasum && dbv && rows > 0 && E > 0 && H > 0 && E % H == 0 && H <= 32 && E <= 256 * QT_HB_MAXC,
-                 "qt_headbias_bwd: bad arguments");
+    QT_CHECK_ARG(dout && asum && bv && dasum && dbv && rows > 0 && E > 0 && H > 0 && E % H == 0 && (E / H) % 4 == 0 && H <= 64 && E <= 256 * QT_HB_MAXC &&
+                 ld % 4 == 0 && qt_aligned16(dout) && qt_aligned16(bv), "qt_headbias_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (!dbv_accumulate) {
         hipError_t e = qt_zero_1d(dbv, E, st);

@@ -258,6 +258,23 @@ def test_linear_emits_the_next_layers_operand_image(ops):
         assert torch.equal(z, ops.linear(plain.reshape(rows, n_mid), w2, b2))
 
 
+@pytest.mark.parametrize('rows,E,H', [(30720, 768, 8), (257, 1024, 8), (64, 96, 3)])
+def test_head_bias_fn(ops, rows, E, H):
+    """out = o + asum[:, head(e)] * b_v[e] (qt_headbias_fwd / qt_headbias_bwd): the value bias of a folded attention, forward and all three
+    gradients against fp64 torch math."""
+    o = rnd(rows, E, seed=51).requires_grad_(True)
+    asum = (1.0 + 0.1 * rnd(rows, H, seed=52)).requires_grad_(True)
+    bv = rnd(E, seed=53).requires_grad_(True)
+    out = ops.HeadBiasFn.apply(o, asum, bv, H)
+    g = rnd(rows, E, seed=54)
+    out.backward(g)
+    od, ad, bd = o.detach().double().requires_grad_(True), asum.detach().double().requires_grad_(True), bv.detach().double().requires_grad_(True)
+    ref = od + ad.repeat_interleave(E // H, dim=1) * bd
+    ref.backward(g.double())
+    assert rel(out.detach(), ref.detach()) < 1e-6
+    assert rel(o.grad, od.grad) < 1e-6 and rel(asum.grad, ad.grad) < 1e-5 and rel(bv.grad, bd.grad) < 1e-5
+
+
 def test_linear_fn_grads(ops):
     x = rnd(5, 7, 96, seed=12).requires_grad_(True)
     w = rnd(130, 96, seed=13, scale=0.1).requires_grad_(True)
