@@ -112,16 +112,41 @@ __global__ __launch_bounds__(256) void qt_add_ln_bwd_kernel(LnArgs p) {
     float gmx[LN_MAX_ADD];
 #pragma unroll
     for (int a = 0; a < LN_MAX_ADD; ++a) gmx[a] = 0.f;
+    // gamma stays in registers; the NEXT row's dy / x̂ are requested before the current row is reduced (a wave owns ~4 rows of a
+    // 30720-row launch: without this every row exposed a full load latency behind two wave reductions)
+    float4 gm[LN_MAXV], nd[LN_MAXV], nx[LN_MAXV];
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int c4 = lane + t * 64;
+        gm[t] = c4 < nv ? *reinterpret_cast<const float4*>(p.gamma + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nd[t] = nx[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < nv && wave_global < p.rows) {
+            nd[t] = *reinterpret_cast<const float4*>(p.dy + (long)wave_global * p.lddy + c4 * 4);
+            nx[t] = *reinterpret_cast<const float4*>(p.xhat + (long)wave_global * p.D + c4 * 4);
+        }
+    }
     for (int row = wave_global; row < p.rows; row += nwaves) {
-        float4 dxh[LN_MAXV], xh[LN_MAXV];
+        float4 dxh[LN_MAXV], xh[LN_MAXV], dcur[LN_MAXV];
+#pragma unroll
+        for (int t = 0; t < LN_MAXV; ++t) { dcur[t] = nd[t]; xh[t] = nx[t]; }
+        const int nrow = row + nwaves;
+        if (nrow < p.rows) {
+#pragma unroll
+            for (int t = 0; t < LN_MAXV; ++t) {
+                const int c4 = lane + t * 64;
+                if (c4 < nv) {
+                    nd[t] = *reinterpret_cast<const float4*>(p.dy + (long)nrow * p.lddy + c4 * 4);
+                    nx[t] = *reinterpret_cast<const float4*>(p.xhat + (long)nrow * p.D + c4 * 4);
+                }
+            }
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < LN_MAXV; ++t) {
             const int c4 = lane + t * 64;
             if (c4 < nv) {
-                const float4 d = *reinterpret_cast<const float4*>(p.dy + (long)row * p.lddy + c4 * 4);
-                const float4 g = *reinterpret_cast<const float4*>(p.gamma + c4 * 4);
-                xh[t] = *reinterpret_cast<const float4*>(p.xhat + (long)row * p.D + c4 * 4);
+                const float4 d = dcur[t];
+                const float4 g = gm[t];
                 dxh[t] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
                 s1 += dxh[t].x + dxh[t].y + dxh[t].z + dxh[t].w;
                 s2 += dxh[t].x * xh[t].x + dxh[t].y * xh[t].y + dxh[t].z * xh[t].z + dxh[t].w * xh[t].w;

@@ -328,7 +328,7 @@ def amax_of(x: Tensor, out: Optional[Tensor] = None, keep: bool = False) -> Tens
 
 
 def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, colsum: Optional[Tensor] = None, keep: bool = False,
-                colsum_accumulate: bool = False) -> SplitImage:
+                colsum_accumulate: bool = False, out: Optional[Tensor] = None) -> SplitImage:
     """fp32 [rows, cols] -> SplitImage.  scaled=True measures max|x| first (one extra read of x) and scales the parts into
     fp16's normal range; pass `amax` when a producer has already measured it."""
     x = as2d(x)
@@ -338,7 +338,7 @@ def split_image(x: Tensor, scaled: bool = False, amax: Optional[Tensor] = None, 
         raise _lib.QTError(f'split_image: {Cc} columns is not a multiple of 32')
     if scaled and amax is None:
         amax = amax_of(x, keep=keep)
-    img = torch.empty((R, Cc), device=x.device, dtype=torch.float32)
+    img = out if (out is not None and out.shape == (R, Cc) and out.is_contiguous()) else torch.empty((R, Cc), device=x.device, dtype=torch.float32)
     rc = _launch('split', 8.0 * R * Cc, (R, Cc), lambda: _lib.load().qt_split_f16(
         _stream(), _ptr(x), _ld(x), R, Cc, _ptr(amax), _ptr(img), 4 * Cc, _ptr(colsum), int(colsum_accumulate)))
     _lib.check(rc, 'qt_split_f16')
@@ -814,10 +814,14 @@ def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     cached = getattr(x, '_qt_img', None)
     if cached is not None and cached[0] == (x._version, x.data_ptr(), pass_epoch) and cached[1].data.shape == x2.shape:
         return cached[1]
+    # A stale image on the same tensor object (an input fed to pass after pass) lends its memory to the new one when no autograd graph can
+    # still hold it (inference): re-allocating a 2 GB image per pass next to its predecessor made the caching allocator fall back to
+    # hipMalloc at the long-video config (host stalls of tens of ms).  Launches are stream-ordered: the old image's readers are ahead.
+    reuse = cached[1].data if (cached is not None and not torch.is_grad_enabled() and not getattr(x, '_qt_is_image', False)) else None
     with torch.no_grad():
         # robust-range mode: activations beyond fp16's range are scaled by their max|x| first (act_amax); by default the parts are unscaled
         am = act_amax(x, x2)
-        img = split_image(x2.detach(), scaled=am is not None, amax=am)
+        img = split_image(x2.detach(), scaled=am is not None, amax=am, out=reuse)
     x._qt_img = ((x._version, x.data_ptr(), pass_epoch), img)
     return img
 
