@@ -708,7 +708,9 @@ class GradLink:
 # below this many rows a Linear stays on the split-in-the-consumer kernels: a handful of 256x256 tiles leaves the chip idle and
 # the operand passes are pure launch latency there (measured: 256-row layers 28 us on qt_gemm_ps vs 17 us on qt_gemm_x3's 64-row tiles)
 plane_min_rows = int(_os.environ.get('QT_PLANE_MIN_ROWS', '2048'))
-plane_dw_min_rows = int(_os.environ.get('QT_PLANE_DW_MIN_ROWS', '8192'))    # below: forward and dX on the pre-split kernel, dW on the small-tile kernel
+plane_dw_min_rows = int(_os.environ.get('QT_PLANE_DW_MIN_ROWS', '2048'))    # below: forward and dX on the pre-split kernel, dW on the small-tile kernel
+# (round 2: 8192 — the pre-split kernel's split-K atomics bound the short-K dW products; with the K splits meeting in a workspace it wins
+# from 2048 rows on: B = 32 shard 8.67 -> 8.50 ms, B = 64 12.59 -> 12.13 ms per captured step)
 
 
 def _plane_ok(rows: int, n_out: int, k_in: int) -> bool:
