@@ -253,7 +253,7 @@ static void launch_cfg(const GemmArgs& a, int transA, int transB, dim3 grid, hip
     else                         hipLaunchKernelGGL((qt_gemm_f32_kernel<TM, TN, true, true, VEC>), grid, dim3(256), 0, st, a);
 }
 
-int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate);   // gemm_plane.hip
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate, float* c_amax);   // gemm_plane.hip
 
 extern "C" int qt_gemm_f32_ws(void* stream, int transA, int transB, int M, int N, int K, float alpha,
                            const float* A, long lda, const float* B, long ldb, float* C, long ldc,
@@ -318,7 +318,7 @@ extern "C" int qt_gemm_f32_ws(void* stream, int transA, int transB, int M, int N
     if (small) { if (vec == 4) launch_cfg<1, 1, 4>(a, transA, transB, grid, st); else launch_cfg<1, 1, 1>(a, transA, transB, grid, st); }
     else       { if (vec == 4) launch_cfg<2, 2, 4>(a, transA, transB, grid, st); else launch_cfg<2, 2, 1>(a, transA, transB, grid, st); }
     QT_CHECK_LAUNCH("qt_gemm_f32");
-    if (use_ws) return qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate);
+    if (use_ws) return qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate, nullptr);
     return QT_OK;
 }
 

@@ -1084,9 +1084,13 @@ extern "C" int qt_split_f16(void* stream, const float* x, long ldx, long R, int 
 }
 
 
-// Sum of the K-split slabs of a workspace GEMM: C[m, n] (+)= sum_z ws[z][m][n], slabs in a fixed order (deterministic, unlike atomics).
-__global__ __launch_bounds__(256) void qt_splitk_reduce_kernel(const float* __restrict__ ws, int split, long mn, int N, float* __restrict__ C, long ldc, int accumulate) {
+// Sum of the K-split slabs of a workspace GEMM: C[m, n] (+)= sum_z ws[z][m][n], slabs in a fixed order (deterministic, unlike atomics);
+// c_amax (nullable, zeroed by the caller): max|C| of the values as stored — what a split launch's own epilogue cannot know.
+__global__ __launch_bounds__(256) void qt_splitk_reduce_kernel(const float* __restrict__ ws, int split, long mn, int N, float* __restrict__ C, long ldc, int accumulate,
+                                                               float* __restrict__ c_amax) {
+    __shared__ float red[4];
     const long n4 = mn >> 2;
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 acc = *reinterpret_cast<const float4*>(ws + i * 4);
         for (int z = 1; z < split; ++z) {
@@ -1097,24 +1101,32 @@ __global__ __launch_bounds__(256) void qt_splitk_reduce_kernel(const float* __re
         float4* dst = reinterpret_cast<float4*>(C + m * ldc + (e - m * N));          // N % 4 == 0: the four columns share a row
         if (accumulate) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
         *dst = acc;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+        if (acc.x != acc.x || acc.y != acc.y || acc.z != acc.z || acc.w != acc.w) mx = __builtin_nanf("");
     }
+    if (c_amax) qt_amax_fold(mx != mx ? __builtin_inff() : mx, red, c_amax);         // (a NaN in C reads as an infinite maximum: the consumer's scale degenerates loudly)
 }
-
-__global__ __launch_bounds__(256) void qt_splitk_reduce1_kernel(const float* __restrict__ ws, int split, long mn, int N, float* __restrict__ C, long ldc, int accumulate) {
+__global__ __launch_bounds__(256) void qt_splitk_reduce1_kernel(const float* __restrict__ ws, int split, long mn, int N, float* __restrict__ C, long ldc, int accumulate,
+                                                                float* __restrict__ c_amax) {
+    __shared__ float red[4];
+    float mx = 0.f;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < mn; e += (long)gridDim.x * 256) {     // any N, any alignment
         float acc = ws[e];
         for (int z = 1; z < split; ++z) acc += ws[(long)z * mn + e];
         const long m = e / N;
         float* dst = C + m * ldc + (e - m * N);
-        *dst = accumulate ? *dst + acc : acc;
+        if (accumulate) acc += *dst;
+        *dst = acc;
+        mx = acc != acc ? __builtin_inff() : fmaxf(mx, fabsf(acc));
     }
+    if (c_amax) qt_amax_fold(mx, red, c_amax);
 }
-int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate) {     // (also used by gemm_split.hip, gemm.hip)
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate, float* c_amax) {     // (also used by gemm_split.hip, gemm.hip)
     const bool vec = N % 4 == 0 && ldc % 4 == 0 && qt_aligned16(C) && qt_aligned16(ws);
     long blocks = (((long)M * N >> (vec ? 2 : 0)) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (!vec) hipLaunchKernelGGL(qt_splitk_reduce1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate);
-    else hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate);
+    if (!vec) hipLaunchKernelGGL(qt_splitk_reduce1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate, c_amax);
+    else hipLaunchKernelGGL(qt_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, split, (long)M * N, N, C, ldc, accumulate, c_amax);
     QT_CHECK_LAUNCH("qt_splitk_reduce");
     return QT_OK;
 }
@@ -1215,9 +1227,9 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);
-    if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate); if (rc) return rc; }
+    if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate, c_amax); if (rc) return rc; }
     if (c_img && !img_ok) return 3;
-    return (c_amax && split_k > 1) ? 2 : QT_OK;
+    return (c_amax && split_k > 1 && !use_ws) ? 2 : QT_OK;          // (the summing pass of a workspace split measures max|C| while it writes C)
 }
 
 // C[M,N] = epilogue(alpha/(s_a s_b) * op(A) op(B)) on split images.

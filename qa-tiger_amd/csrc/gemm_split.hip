@@ -531,7 +531,7 @@ int qt_gemm_sk(void* stream, int half_type, int transA, int transB, int M, int N
                float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* a_colsum,
                int batch, long a_bs, long b_bs, long c_bs, const float* a_amax, const float* b_amax, float* c_amax);
 
-int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate);   // gemm_plane.hip
+int qt_splitk_reduce(void* stream, const float* ws, int split, int M, int N, float* C, long ldc, int accumulate, float* c_amax);   // gemm_plane.hip
 
 extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, int M, int N, int K, float alpha,
                           const float* A, long lda, const float* B, long ldb, float* C, long ldc,
@@ -653,7 +653,7 @@ extern "C" int qt_gemm_x3(void* stream, int half_type, int transA, int transB, i
         else qt_x3_small_3(a, transA, transB, grid, st);
     }
     QT_CHECK_LAUNCH("qt_gemm_x3");
-    if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate); if (rc) return rc; }
+    if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate, c_amax); if (rc) return rc; return QT_OK; }   // (the summing pass measured max|C|)
     return cmax_skipped ? 2 : QT_OK;
 }
 #endif  // QT_X3_PART == 0
