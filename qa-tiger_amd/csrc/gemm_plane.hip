@@ -105,7 +105,7 @@ template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4, int NWM = 2, int 
 __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
     if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
-    static_assert(MF == 0 || (FMT == 0 && NWM == 2), "16x16x32 form: fp16 lines, 8 waves");
+    static_assert(MF == 0 || (NWM == 2 && (FMT == 0 || SWAP)), "16x16 forms: 8 waves; the fp8 one in the C^T orientation");
     constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
     static_assert((NWM == 2 && (WMT == 4 || ((WMT == 3 || WMT == 2) && !AKS && FMT == 0))) || (NWM == 4 && WMT == 2 && FMT == 0),
                   "tile shapes: 8 waves x (128|96|64) x 64, or 16 waves x 64 x 64");
@@ -380,6 +380,33 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
         });
     };
 
+    // fp8 lines on v_mfma_scale_f32_16x16x128_f8f6f4: lane (r16, g4) supplies row r16 of a 16-row tile, k = 32 g4 .. 32 g4 + 31 = the 16-byte
+    // slots 2 g4 and 2 g4 + 1 of the row's line (both operands use the same lane -> k assignment); ONE MFMA per tile and 128-k line:
+    // 24 ds_read_b128 and 32 MFMAs per K step.  Same reasoning as the fp16 16x16x32 form: equal cycles per FLOP, higher sustained clock.
+    auto compute8_16 = [&](unsigned sbase, unsigned sbase_b, auto&& issue) {
+        typedef int intx8 __attribute__((ext_vector_type(8)));
+        const int r16 = lane & 15, g4 = lane >> 4, x16 = (r16 >> 1) & 7;
+        const unsigned oa0 = (unsigned)((wm * (WMT * 32) + r16) * 128 + (((2 * g4) ^ x16) * 16)), oa1 = (unsigned)((wm * (WMT * 32) + r16) * 128 + (((2 * g4 + 1) ^ x16) * 16));
+        const unsigned ob0 = (unsigned)((wn * 64 + r16) * 128 + (((2 * g4) ^ x16) * 16)), ob1 = (unsigned)((wn * 64 + r16) * 128 + (((2 * g4 + 1) ^ x16) * 16));
+        auto pack = [](const uint4& lo, const uint4& hi) {
+            intx8 v; v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w; v[4] = (int)hi.x; v[5] = (int)hi.y; v[6] = (int)hi.z; v[7] = (int)hi.w;
+            return v;
+        };
+        intx8 vb[2 * WNT], va[2];
+#pragma unroll
+        for (int jt = 0; jt < 2 * WNT; ++jt) vb[jt] = pack(lds_u4(sbase_b + ob0 + jt * 2048), lds_u4(sbase_b + ob1 + jt * 2048));
+        va[0] = pack(lds_u4(sbase + oa0), lds_u4(sbase + oa1));
+        p_static_for<NS>([&](auto IT) {
+            constexpr int it = decltype(IT)::value, cur = it & 1;
+            if constexpr (it + 1 < NS) va[cur ^ 1] = pack(lds_u4(sbase + oa0 + (it + 1) * 2048), lds_u4(sbase + oa1 + (it + 1) * 2048));
+            issue(IT);
+            p_static_for<2 * WNT>([&](auto J) {
+                constexpr int jt = decltype(J)::value;
+                acc16[it][jt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vb[jt], va[cur], acc16[it][jt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            });
+        });
+    };
+
     // 1 / (s_a s_b) from the operands' max|x| records, read once (all 64 lanes active here)
     float scale_ab = 1.0f;
     if (p.a_amax) { const float am = qt_amax_read(p.a_amax); scale_ab *= (FMT == 1 ? qt_fp8_scale(am) : qt_plane_scale(am)); }
@@ -442,7 +469,8 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                 });
             };
             if (!(p.debug & 4)) {
-                if constexpr (FMT == 1) compute8((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
+                if constexpr (FMT == 1 && MF == 1) compute8_16((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
+                else if constexpr (FMT == 1) compute8((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
                 else if constexpr (MF == 1) compute16((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
                 else compute((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER), issue);
             }
@@ -784,7 +812,11 @@ QT_PS_DECL(qt_ps_launch_mf0_t4) { QT_PS_TALL(0); }
 #elif QT_PS_PART == 2
 QT_PS_DECL(qt_ps_launch_mf0_t32) { QT_PS_SHORT(0); }
 #elif QT_PS_PART == 3
-QT_PS_DECL(qt_ps_launch_fp8) { if (swap) QT_PS_GO(false, false, true, 1); else QT_PS_GO(false, false, false, 1); }
+QT_PS_DECL(qt_ps_launch_fp8) {          // (wmt carries the MFMA shape here: 1 = the 16x16x128 form, C^T orientation only)
+    if (swap && wmt == 1) QT_PS_GO(false, false, true, 1, 4, 2, 1);
+    else if (swap) QT_PS_GO(false, false, true, 1);
+    else QT_PS_GO(false, false, false, 1);
+}
 #elif QT_PS_PART == 4
 QT_PS_DECL(qt_ps_launch_mf1_t4) { QT_PS_TALL(1); }
 #elif QT_PS_PART == 5
@@ -1223,7 +1255,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     // the image of C rides on the 16x16x32 C^T epilogue of an unsplit launch; otherwise it is not written (return 3: the caller splits C)
     const bool img_ok = c_img && fmt == 0 && mf && swap && split_k == 1 && N % 32 == 0 && ld_img % 128 == 0 && qt_aligned16(c_img);
     a.c_img = img_ok ? (char*)c_img : nullptr; a.ld_img = ld_img;
-    if (fmt == 1) qt_ps_launch_fp8(a, 0, 0, swap, 4, grid, st);
+    if (fmt == 1) qt_ps_launch_fp8(a, 0, 0, swap, mf ? 1 : 0, grid, st);
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);
