@@ -1120,7 +1120,10 @@ class AttentionFn(torch.autograd.Function):
         if is_img:
             # `o` holds the split image of the attention output, not fp32 rows: it may only feed a Linear on the pre-split path, which
             # finds the image here (input_image) and checks the flag
-            img = SplitImage(o, o.shape[0], o.shape[1], None)
+            # (the image record holds a detached alias of the buffer, not `o` itself: `o -> attribute -> SplitImage -> o` would be a
+            # reference cycle that keeps the tensor AND the autograd graph behind it alive until Python's cyclic collector happens to
+            # run — +38 MB per step at the primary config over a 400-step soak before this was found)
+            img = SplitImage(o.detach(), o.shape[0], o.shape[1], None)
             o._qt_img = ((o._version, o.data_ptr(), pass_epoch), img)
             o._qt_is_image = True
         return o
