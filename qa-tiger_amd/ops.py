@@ -819,7 +819,10 @@ def input_image(x: Tensor, x2: Tensor) -> SplitImage:
     # A stale image on the same tensor object (an input fed to pass after pass) lends its memory to the new one when no autograd graph can
     # still hold it (inference): re-allocating a 2 GB image per pass next to its predecessor made the caching allocator fall back to
     # hipMalloc at the long-video config (host stalls of tens of ms).  Launches are stream-ordered: the old image's readers are ahead.
-    reuse = cached[1].data if (cached is not None and not torch.is_grad_enabled() and not getattr(x, '_qt_is_image', False)) else None
+    # (only for the SAME contents — version and address unchanged, an earlier pass of this very tensor: a graph that still holds the old
+    # image then finds identical bytes in it)
+    reuse = cached[1].data if (cached is not None and cached[0][:2] == (x._version, x.data_ptr()) and not torch.is_grad_enabled()
+                               and not getattr(x, '_qt_is_image', False)) else None
     with torch.no_grad():
         # robust-range mode: activations beyond fp16's range are scaled by their max|x| first (act_amax); by default the parts are unscaled
         am = act_amax(x, x2)
