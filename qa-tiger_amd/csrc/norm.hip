@@ -9,6 +9,7 @@
 // rows, the row kept in registers, mean / variance by wavefront shuffles, one
 // write of y plus the normalised row (x̂) and 1/σ that the backward needs.
 #include "qt_common.h"
+#include <stdlib.h>
 
 #define LN_MAXV 4          // float4 per lane  => D <= 1024
 #define LN_MAX_ADD 4
@@ -261,7 +262,12 @@ extern "C" int qt_add_ln_bwd(void* stream, int rows, int D, int n_add,
     else if (dbeta == dgamma + D) e = qt_zero_1d(dgamma, 2L * D, st);     // one launch when the two live side by side (ops.py allocates them so)
     else { e = qt_zero_1d(dgamma, D, st); if (e == hipSuccess) e = qt_zero_1d(dbeta, D, st); }
     if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "qt_add_ln_bwd: memset: %s", hipGetErrorString(e));
-    const int blocks = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);   // 2048 x 4 waves: 32 waves per CU
+    // 512 blocks x 4 waves (8 waves per CU, each prefetching its next row): every block ends with 2 D global atomics into the SAME 2 D
+    // addresses, and same-address atomics serialise in the L2 — with 2048 blocks that tail was ~80 us of every launch, whatever its size
+    // (15360 x 768, one addend: 107 us; 512 blocks: 44 us; `tools/ln_blocks_sweep.sh`).  QT_LN_BLOCKS overrides (A/B).
+    int cap = 512;
+    { const char* e = getenv("QT_LN_BLOCKS"); if (e && atoi(e) > 0) cap = atoi(e); }
+    const int blocks = (int)((rows + 3) / 4 < cap ? (rows + 3) / 4 : cap);
     hipLaunchKernelGGL(qt_add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
     QT_CHECK_LAUNCH("qt_add_ln_bwd");
     return QT_OK;
