@@ -267,7 +267,7 @@ bool qt_gemm_sk_wants(int M, int N, int K, int batch) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
     if (M < 16 || N < 32 || tiles > 512) return false;
     if (batch > 1 && K <= 768) return true;             // head-batched products of a small batch (256x96x768 x8: 24.9 -> 18.2 us; the tiled kernel would split K with atomics)
-    return K <= 384 || (K <= 768 && tiles >= 128);
+    return K <= 384 || (K <= 768 && tiles >= 48);        // (with the tiled kernel's K splits meeting in a workspace + summing pass: 256x768x768 18.4 us tiled vs 18.6 here, 512x768x768 21.1 vs 18.3 — one launch instead of two)
 }
 
 // Same contract as qt_gemm_x3 (include/qatiger.h); returns 2 when a grid-level K split kept it from measuring max|C|.

@@ -217,7 +217,8 @@ def gemm(a: Tensor, b: Tensor, *, trans_a: bool = False, trans_b: bool = True, o
         float(drop_p), C.c_ulonglong(seed), int(accumulate), int(split_k), *btail, _ptr(ws), ws.numel() if ws is not None else 0))
     _lib.check(rc, 'qt_gemm_f32')
     if a_colsum is not None:                           # the fp32 kernel has no fused column sum
-        _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), 0), 'qt_colsum')
+        # (accumulate: C and a_colsum both hold earlier contributions — a shared weight's second use adds to its claimed slices)
+        _lib.check(_lib.load().qt_colsum(_stream(), _ptr(a), _ld(a), a.shape[0], a.shape[1], _ptr(a_colsum), int(accumulate)), 'qt_colsum')
     if c_amax is not None:                             # ... and does not measure max|C|: one explicit pass into the caller's record
         _lib.check(_launch('split', 4.0 * out.numel(), ('amax',) + tuple(out.shape), lambda: _lib.load().qt_amax_f32(
             _stream(), _ptr(out), _ld(out), out.shape[0], out.shape[1], _ptr(c_amax), 1)), 'qt_amax_f32')

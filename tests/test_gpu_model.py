@@ -269,8 +269,12 @@ def test_full_size_invariances(qt, synth):
     with torch.no_grad():
         base = model(inp)['out']
         again = model(inp)['out']
-        # no GEMM of the forward meets its K splits in atomics any more (workspace / in-workgroup split-K): the same bits every run
-        assert torch.equal(base, again)
+        # no GEMM of the forward meets its K splits in atomics any more (workspace / in-workgroup split-K): the same bits every run.
+        # (The diagnostic modes QT_GEMM=fp32 / bf16x1 send the head-batched products to kernels that still split K with atomics.)
+        if qt.ops.precision['fwd'] == 'f16x3':
+            assert torch.equal(base, again)
+        else:
+            assert float((base - again).abs().max()) / float(base.abs().max()) < 1e-5
         pp = torch.randperm(cfg.P, device=DEV)
         out_p = model({**inp, 'patch': inp['patch'][:, :, pp]})['out']
         wp = torch.randperm(cfg.L, device=DEV)
