@@ -271,7 +271,8 @@ def test_full_size_invariances(qt, synth):
         again = model(inp)['out']
         # no GEMM of the forward meets its K splits in atomics any more (workspace / in-workgroup split-K): the same bits every run.
         # (The diagnostic modes QT_GEMM=fp32 / bf16x1 send the head-batched products to kernels that still split K with atomics.)
-        if qt.ops.precision['fwd'] == 'f16x3':
+        import os
+        if qt.ops.precision['fwd'] == 'f16x3' and not os.environ.get('QT_PS_ATOMIC'):     # (QT_PS_ATOMIC=1: round 2's atomics, for A/B runs)
             assert torch.equal(base, again)
         else:
             assert float((base - again).abs().max()) / float(base.abs().max()) < 1e-5
