@@ -19,7 +19,8 @@ SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_skinny.hip', 'gemm_plane.hip', 'a
 GFX = 'gfx950'
 ABI_VERSION = 211          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
-FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result']
+W4 = bool(os.environ.get('QT_PS_WITH_W4'))      # also build gemm_plane.hip's four-wave layout (an experiment: csrc/gemm_plane.hip "NWN")
+FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result'] + (['-DQT_PS_WITH_W4'] if W4 else [])
 
 
 class QTError(RuntimeError):
@@ -74,7 +75,7 @@ def _build_locked(srcs, verbose: bool, force: bool = False) -> str:
     jobs = []
     for src in srcs:
         base = os.path.splitext(os.path.basename(src))[0]
-        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else ((range(6), 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
+        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else ((range(10 if W4 else 8), 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
         for part in parts:
             obj = os.path.join(objdir, base + ('' if part is None else f'_p{part}') + '.o')
             jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-D{macro}={part}']), obj))

@@ -101,17 +101,35 @@ template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_
 // MF: MFMA shape of the fp16 path.  0 = v_mfma_f32_32x32x16_f16 (two per 32-k line and 32x32 tile); 1 = v_mfma_f32_16x16x32_f16 (one per
 //     line and 16x16 tile: the same cycles per FLOP, the same LDS bytes per wave tile, but the chip holds a higher clock on this shape
 //     under a matrix-dense load, MI355X_MICROARCH.md "DVFS give-back" item 7).  Row-form operands, SWAP orientation.
-template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4, int NWM = 2, int MF = 0>
-__global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
+// NWN: wave columns.  4 = waves of (32 WMT) x 64; 2 = FOUR waves (2 x 2) of 128 x 128 on the same 256 x 256 tile (WMT = 4, the 16x16x32 form):
+//      one wave per SIMD with all 256 accumulators in AGPRs; per K step a wave reads 32 fragments for 192 MFMAs instead of 24 for 96,
+//      i.e. a third less LDS traffic per MFMA, and four waves meet at the per-step barrier instead of eight.
+//      Measured and NOT shipped (profiles/r03_pipe_ab.txt): bit-identical results; with the barrier-first loop 5-13 % slower than eight waves
+//      (one wave per SIMD: nothing covers its LDS-DMA issue and its waits); with the late-barrier pipeline and two B fragment sets (PIPE 2)
+//      2-5 % FASTER on the long-K small-output products (2304x768x215040: 1.73 vs 1.77 ms) but 15-25 % slower wherever the tile write-out
+//      matters (each wave issues 64 store instructions instead of 32, and the stores are issue-bound).
+// PIPE (16x16x32 form): the per-K-step barrier sits in front of the LAST segment of a step instead of in front of the first, and the last
+//      segment re-loads the B fragments (each pair right after the three MFMAs that were its last readers) and the first A fragment from
+//      the NEXT step's stages: when a step begins its first MFMA has its operands in registers, so the matrix pipe no longer idles through
+//      barrier + ~20 KiB of fragment reads per wave at every step.  Transfers run one step further ahead on the same stages (B(t+2) and
+//      A(t+3) go out right after the barrier of step t, which is also the point where every wave has finished reading B(t) and A(t)).
+//      PIPE = 2 (four-wave layout: 256 of its 512 registers hold the accumulators, ~130 are free): TWO B fragment sets — the next step's
+//      B fragments are all requested right after the barrier, in front of the last segment's MFMAs, instead of pair by pair behind them.
+template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4, int NWM = 2, int MF = 0, int NWN = 4, int PIPE = 0>
+__global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p) {
     if (p.salt && p.drop_p > 0.f) p.drop_seed += *p.salt;
     static_assert(FMT == 0 || (!AKS && !BKS), "fp8 lines are consumed K-contiguous only");
     static_assert(MF == 0 || (NWM == 2 && (FMT == 0 || SWAP)), "16x16 forms: 8 waves; the fp8 one in the C^T orientation");
     constexpr int KS = FMT == 1 ? 128 : 32;            // k per step
     static_assert((NWM == 2 && (WMT == 4 || ((WMT == 3 || WMT == 2) && !AKS && FMT == 0))) || (NWM == 4 && WMT == 2 && FMT == 0),
                   "tile shapes: 8 waves x (128|96|64) x 64, or 16 waves x 64 x 64");
-    constexpr int WNT = 2, NWN = 4;                   // wave tile (32 WMT) x 64 = WMT x 2 MFMA tiles of 32 x 32
+    static_assert(PIPE == 0 || (MF == 1 && FMT == 0), "the late-barrier pipeline: the fp16 16x16x32 form");
+    static_assert(PIPE != 2 || NWN == 2, "two B fragment sets: only the four-wave layout has the registers");
+    static_assert(NWN == 4 || (NWN == 2 && NWM == 2 && WMT == 4 && MF == 1 && FMT == 0), "four waves of 128 x 128: the fp16 16x16x32 form only");
+    constexpr int WNT = 8 / NWN;                      // wave tile (32 WMT) x (32 WNT): WMT x WNT MFMA tiles of 32 x 32
     constexpr int BM = NWM * WMT * 32, BN = 256, GM = 4;
-    constexpr int NBP = 32 / (NWM * NWN);              // 1 KiB DMA pieces of the B tile per wave (A: WMT per wave)
+    constexpr int NBP = 32 / (NWM * NWN);              // 1 KiB DMA pieces of the B tile per wave
+    constexpr int NAP = 4 * WMT / NWN;                 // ... and of the A tile (BM / 8 pieces over NWM x NWN waves)
     constexpr int NS = 2 * WMT;                       // compute segments per K step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -135,18 +153,20 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
         const int gm_rows = min(GM, p.tiles_m - group * GM);
         const int within = t - group * (GM * p.tiles_n);
         const int tile_n = within / gm_rows;
-        m0 = (group * GM + (within - tile_n * gm_rows)) * BM;
-        n0 = tile_n * BN;
+        // (the divisions above run on the vector unit; the tile coordinates feed the wave-uniform DMA base addresses, which must be scalar)
+        m0 = __builtin_amdgcn_readfirstlane((group * GM + (within - tile_n * gm_rows)) * BM);
+        n0 = __builtin_amdgcn_readfirstlane(tile_n * BN);
+        ksplit = __builtin_amdgcn_readfirstlane(ksplit);
         kbeg = ksplit * p.k_per_split;
         kend = min(p.K, kbeg + p.k_per_split);
     };
 
     // ---- per-lane DMA source offsets (bytes from the operand base), 4 pieces of 1 KiB per operand per wave
-    unsigned offA[WMT], offB[NBP];
+    unsigned offA[NAP], offB[NBP];
     auto set_offsets = [&]() {
 #pragma unroll
-        for (int i = 0; i < WMT; ++i) {
-            const int pc = wave * WMT + i;                       // piece 0..8*WMT-1 of the A tile
+        for (int i = 0; i < NAP; ++i) {
+            const int pc = wave * NAP + i;                       // piece 0..BM/8-1 of the A tile
             if (!AKS) {                                          // rows pc*8 .. pc*8+7, one 128-B line each
                 const int row = pc * 8 + (lane >> 3);
                 const int sl = (lane & 7) ^ ((row >> 1) & 7);
@@ -175,13 +195,13 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
     // — BASELINE config 4 at B = 128 — is 6.6 GB), m0 is uniform and current whenever a DMA of this tile is issued.
     auto dma_a = [&](int k0, int stage) {
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
-        const unsigned la = lds0 + stage * P_OPER + wave * (WMT * 1024);
+        const unsigned la = lds0 + stage * P_OPER + wave * (NAP * 1024);
 #pragma unroll
-        for (int i = 0; i < WMT; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
+        for (int i = 0; i < NAP; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
     auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
-        qt_dma16(lds0 + stage * P_OPER + wave * (WMT * 1024) + i * 1024, sa, offA[i]);
+        qt_dma16(lds0 + stage * P_OPER + wave * (NAP * 1024) + i * 1024, sa, offA[i]);
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
         const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
@@ -205,8 +225,8 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
         for (int c = 0; c < 4; ++c) {
             if (!AKS) fa[c] = (unsigned)((wm * (WMT * 32) + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);   // c = hl*2 + s
             else      fa[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wm * 2 * WMT) * 64 + ((c ^ q) * 64));   // c = unit & 3
-            if (!BKS) fb[c] = (unsigned)((wn * 64 + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
-            else      fb[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
+            if (!BKS) fb[c] = (unsigned)((wn * (WNT * 32) + r) * 128 + (((c >> 1) * 4 + 2 * (c & 1) + h) ^ x) * 16);
+            else      fb[c] = (unsigned)(((8 * (g >> 1) + q) * 1024) + 32 * (g & 1) + 8 * pp + (wn * 2 * WNT) * 64 + ((c ^ q) * 64));
         }
     }
 
@@ -342,8 +362,8 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
         for (int c = 0; c < 4; ++c) {                  // row form: c = hl (0, 1);  column form: c = unit & 3
             if (!AKS) fa16[c] = (unsigned)((wm * (WMT * 32) + r16) * 128 + ((((c & 1) * 4 + g4) ^ x16) * 16));
             else      fa16[c] = (unsigned)((8 * g4 + q) * 1024 + 8 * pp + (wm * 2 * WMT) * 64 + ((c ^ q) * 64));
-            if (!BKS) fb16[c] = (unsigned)((wn * 64 + r16) * 128 + ((((c & 1) * 4 + g4) ^ x16) * 16));
-            else      fb16[c] = (unsigned)((8 * g4 + q) * 1024 + 8 * pp + (wn * 4) * 64 + ((c ^ q) * 64));
+            if (!BKS) fb16[c] = (unsigned)((wn * (WNT * 32) + r16) * 128 + ((((c & 1) * 4 + g4) ^ x16) * 16));
+            else      fb16[c] = (unsigned)((8 * g4 + q) * 1024 + 8 * pp + (wn * 2 * WNT) * 64 + ((c ^ q) * 64));
         }
     }
     auto compute16 = [&](unsigned sbase, unsigned sbase_b, auto&& issue) {
@@ -378,6 +398,70 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                 acc16[it][jt] = mm(ah[cur], bh[jt], acc16[it][jt]);
             });
         });
+    };
+
+    // ---- PIPE: fragments that live across K steps
+    uint4 pbh[PIPE == 2 ? 2 : 1][PIPE ? 2 * WNT : 1], pbl[PIPE == 2 ? 2 : 1][PIPE ? 2 * WNT : 1], pal[2], pah[2];
+    auto frag16 = [&](unsigned base, const unsigned* f, bool kslow, int t, int hl) -> uint4 {
+        if (!kslow) return lds_u4(base + f[hl] + t * 2048);
+        const unsigned kb = base + (unsigned)((t >> 2) * 256 + 32 * (t & 1)) + f[2 * ((t >> 1) & 1) + hl];
+        const uint2 v0 = lds_tr(kb), v1 = lds_tr(kb + 4096);
+        return make_uint4(v0.x, v0.y, v1.x, v1.y);
+    };
+    auto first_frags = [&](unsigned sA, unsigned sB) {       // a tile's first step: nothing to hide them behind
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int jt = 0; jt < 2 * WNT; ++jt) pbh[0][jt] = frag16(sB, fb16, BKS, jt, 0);
+            pal[0] = frag16(sA, fa16, AKS, 0, 1);
+            pah[0] = frag16(sA, fa16, AKS, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < 2 * WNT; ++jt) pbl[0][jt] = frag16(sB, fb16, BKS, jt, 1);
+        }
+    };
+    // one K step; HAS_NEXT: the tile has another step (stages sA1 / sB1), whose barrier `sync` and first fragments belong to this step's last segment
+    // PAR (PIPE = 2): the B fragment set this step multiplies with; the next step's go into the other one
+    // (Tried on top, no gain: the second wave of every SIMD issuing its LDS-DMA pieces in the MIDDLE of a segment's MFMAs instead of in front
+    //  of them, so that one wave multiplies while the other's issue stream is held by a DMA instruction: +-0.5 % on the row-form products,
+    //  -9...-12 % on the dX orientation — profiles/r03_pipe_ab.txt section 6.)
+    auto compute16p = [&](auto HAS_NEXT, auto PAR, unsigned sA, unsigned sA1, unsigned sB1, auto&& issue, auto&& sync) {
+        constexpr bool has_next = decltype(HAS_NEXT)::value;
+        constexpr int bs = PIPE == 2 ? decltype(PAR)::value : 0, bn = PIPE == 2 ? (bs ^ 1) : 0;
+        auto mm = [&](const uint4& x, const uint4& y, floatx4_t c) {
+            if (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, y), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+            else      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+        };
+        if constexpr (PIPE) {
+            p_static_for<NS>([&](auto IT) {
+                constexpr int it = decltype(IT)::value, cur = it & 1;
+                if constexpr (it + 1 < NS) {
+                    pal[cur ^ 1] = frag16(sA, fa16, AKS, it + 1, 1);
+                    pah[cur ^ 1] = frag16(sA, fa16, AKS, it + 1, 0);
+                } else if constexpr (has_next) {
+                    sync();                                          // every wave has read all of A(t) (and B(t), one step ago); A(t+1), B(t+1) have landed
+                    if constexpr (PIPE == 2) {
+#pragma unroll
+                        for (int jt = 0; jt < 2 * WNT; ++jt) pbh[bn][jt] = frag16(sB1, fb16, BKS, jt, 0);
+                    }
+                    pal[cur ^ 1] = frag16(sA1, fa16, AKS, 0, 1);     // (NS is even: the next step's segment 0 reads slot 0)
+                    pah[cur ^ 1] = frag16(sA1, fa16, AKS, 0, 0);
+                    if constexpr (PIPE == 2) {
+#pragma unroll
+                        for (int jt = 0; jt < 2 * WNT; ++jt) pbl[bn][jt] = frag16(sB1, fb16, BKS, jt, 1);
+                    }
+                }
+                issue(IT);
+                p_static_for<2 * WNT>([&](auto J) {
+                    constexpr int jt = decltype(J)::value;
+                    acc16[it][jt] = mm(pal[cur], pbh[bs][jt], acc16[it][jt]);
+                    acc16[it][jt] = mm(pah[cur], pbl[bs][jt], acc16[it][jt]);
+                    acc16[it][jt] = mm(pah[cur], pbh[bs][jt], acc16[it][jt]);
+                    if constexpr (PIPE == 1 && it + 1 == NS && has_next) {   // the last readers of this B pair have issued: fetch the next step's pair
+                        pbh[0][jt] = frag16(sB1, fb16, BKS, jt, 0);
+                        pbl[0][jt] = frag16(sB1, fb16, BKS, jt, 1);
+                    }
+                });
+            });
+        }
     };
 
     // fp8 lines on v_mfma_scale_f32_16x16x128_f8f6f4: lane (r16, g4) supplies row r16 of a 16-row tile, k = 32 g4 .. 32 g4 + 31 = the 16-byte
@@ -422,12 +506,20 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
     // Stages are addressed by running step counters that continue across tiles: A step g lives in stage g % 3, B step g in g & 1.
     int sa_cur = 0, gb = 0;                            // A stage of the current step; B step parity
     auto nxt3 = [](int s) { return s == P_A_STAGES - 1 ? 0 : s + 1; };
-    {   // first tile: A(0), A(1), B(0)
+    auto tile_prologue = [&]() {     // !PIPE: A(0), A(1), B(0);  PIPE: A(0), B(0), A(1), B(1), A(2) — in this order (the counted waits rely on it)
         const int nk0 = (kend - kbeg) / KS;
-        dma_a(kbeg, sa_cur);
-        if (nk0 > 1) dma_a(kbeg + KS, nxt3(sa_cur));
-        dma_b(kbeg, gb & 1);
-    }
+        if constexpr (PIPE) {
+            dma_a(kbeg, sa_cur);
+            dma_b(kbeg, gb & 1);
+            if (nk0 > 1) { dma_a(kbeg + KS, nxt3(sa_cur)); dma_b(kbeg + KS, (gb + 1) & 1); }
+            if (nk0 > 2) dma_a(kbeg + 2 * KS, nxt3(nxt3(sa_cur)));
+        } else {
+            dma_a(kbeg, sa_cur);
+            if (nk0 > 1) dma_a(kbeg + KS, nxt3(sa_cur));
+            dma_b(kbeg, gb & 1);
+        }
+    };
+    tile_prologue();
     for (;;) {
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
@@ -442,24 +534,86 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
                 for (int j = 0; j < 2 * WNT; ++j) acc16[i][j] = floatx4_t{0.f, 0.f, 0.f, 0.f};
         }
         const int nk = (kend - kbeg) / KS;
+        if constexpr (PIPE) {
+            // tile start: the prologue's transfers (and the previous tile's write-out: one in-order counter) are complete in every wave
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            first_frags((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER));
+            auto step = [&](const int t, auto HAS_NEXT, auto PAR) {
+                const int kb1 = kbeg + (t + 1) * KS, ka2 = kbeg + (t + 2) * KS;
+                const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
+                // Transfers are issued in CYCLES that open right after a step's barrier: cycle(t) = B(t+2) pieces, then A(t+3) pieces; its first
+                // slot is the last segment of step t, the others are segments 0 .. NS-2 of step t+1.  (cycle(-1) = B(1), A(2) is the prologue's.)
+                // At the barrier of step t the youngest transfers are the NAP pieces of A(t+2) (if it exists): everything older has landed.
+                auto issue = [&](auto SEG) {
+                    constexpr int seg = decltype(SEG)::value;
+                    constexpr int NP = NBP + NAP;
+                    p_static_for<NP>([&](auto PC) {
+                        constexpr int pc = decltype(PC)::value;
+                        constexpr int slot = pc < NBP ? (pc * 2) / NBP : 2 + ((pc - NBP) * (NS - 2)) / NAP;     // B first (it has one step to land), A behind it
+                        if constexpr (slot == 0) {
+                            if constexpr (seg == NS - 1) {           // cycle(t): B(t+2) -> the stage that held B(t), A(t+3) -> the stage that held A(t)
+                                if constexpr (pc < NBP) { if (t + 2 < nk) dma_b1(kbeg + (t + 2) * KS, gb & 1, pc); }
+                                else { if (t + 3 < nk) dma_a1(kbeg + (t + 3) * KS, sa_cur, pc - NBP); }
+                            }
+                        } else if constexpr (slot - 1 == seg) {      // cycle(t-1): B(t+1), A(t+2)
+                            if (t > 0) {
+                                if constexpr (pc < NBP) { if (t + 1 < nk) dma_b1(kb1, stb, pc); }
+                                else { if (t + 2 < nk) dma_a1(ka2, sta, pc - NBP); }
+                            }
+                        }
+                    });
+                };
+                auto sync = [&]() {
+                    if (t + 2 < nk) {
+                        if constexpr (NAP == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                        else if constexpr (NAP == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                        else if constexpr (NAP == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                };
+                const unsigned sA = (unsigned)(sa_cur * P_OPER), sA1 = (unsigned)(nxt3(sa_cur) * P_OPER), sB1 = (unsigned)(P_B_BASE + ((gb + 1) & 1) * P_OPER);
+                compute16p(HAS_NEXT, PAR, sA, sA1, sB1, issue, sync);
+                sa_cur = nxt3(sa_cur);
+                ++gb;
+            };
+            using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+            if constexpr (PIPE == 2) {           // two steps per trip: the fragment sets alternate
+                int t = 0;
+                for (; t + 2 < nk; t += 2) { step(t, std::true_type{}, P0{}); step(t + 1, std::true_type{}, P1{}); }
+                if (t + 2 == nk) { step(t, std::true_type{}, P0{}); step(t + 1, std::false_type{}, P1{}); }
+                else step(t, std::false_type{}, P0{});
+            } else {
+                for (int t = 0; t + 1 < nk; ++t) step(t, std::true_type{}, P0{});
+                step(nk - 1, std::false_type{}, P0{});
+            }
+            // every wave is done reading the last step's stages before anyone's next-tile prologue overwrites them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else
         for (int t = 0; t < nk; ++t) {
             // Issue order is B(t+1) then A(t+2) at every step, so when step t opens the only younger transfers than the ones it
             // reads (A(t): two steps old, B(t): one step old) are the 4 pieces of A(t+1) — if that was issued at all.  The first
             // step of a tile also drains the previous tile's write-out (in-order counter; a counted wait would need the exact
             // number of stores, which ragged tiles make data-dependent).
             if (t > 0 && t + 1 < nk) {
-                if constexpr (WMT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if constexpr (WMT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // (always: the pieces of A(t+1) are the youngest transfers)
+                if constexpr (NAP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (NAP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (NAP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // (always: the NAP pieces of A(t+1) are the youngest transfers)
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // every wave's pieces of this step have landed; the stages of step t-1 are free
             asm volatile("" ::: "memory");
             const bool do_b = (t + 1 < nk) && !(p.debug & 2), do_a = (t + 2 < nk) && !(p.debug & 2);
             const int kb1 = kbeg + (t + 1) * KS, ka2 = kbeg + (t + 2) * KS;
             const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
-            auto issue = [&](auto SEG) {                   // pieces 0-3: B(t+1), then the WMT pieces of A(t+2) — this order is what vmcnt(WMT) counts on
+            auto issue = [&](auto SEG) {                   // pieces 0..NBP-1: B(t+1), then the NAP pieces of A(t+2) — this order is what vmcnt(NAP) counts on
                 constexpr int seg = decltype(SEG)::value;
-                constexpr int NP = NBP + WMT;                  // pieces per wave per step, spread evenly over the NS segments in this order
+                constexpr int NP = NBP + NAP;                  // pieces per wave per step, spread evenly over the NS segments in this order
                 p_static_for<NP>([&](auto PC) {
                     constexpr int pc = decltype(PC)::value;
                     if constexpr ((pc * NS) / NP == seg) {
@@ -489,10 +643,7 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
             set_offsets();
             // next tile's A(0), A(1), B(0): their stages were last read at steps g-2, g-1, g-1 of the running count, and every wave
             // has passed the barrier of step g (the last one of this tile), i.e. has finished multiplying step g-1
-            const int nk1 = (kend - kbeg) / KS;
-            dma_a(kbeg, sa_cur);
-            if (nk1 > 1) dma_a(kbeg + KS, nxt3(sa_cur));
-            dma_b(kbeg, gb & 1);
+            tile_prologue();
         }
         if ((p.debug & 1) && (MF ? acc16[0][0][0] : acc[0][0][0]) != 12345.678f) { if (!more) break; continue; }
         // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
@@ -778,20 +929,33 @@ __global__ __launch_bounds__(NWM * 256) void qt_gemm_ps_kernel(PlaneArgs p) {
     }
 }
 
-// This file is compiled six times (qa-tiger_amd/_lib.py): -DQT_PS_PART=1..5 each instantiate one group of the GEMM kernel (MFMA shape x
-// tile heights; the fp8 form), part 0 holds the operand passes and the C entry points.  The parts build in parallel.
+// This file is compiled eight times (qa-tiger_amd/_lib.py): -DQT_PS_PART=1..7 each instantiate one group of the GEMM kernel (MFMA shape x
+// tile heights x loop form; the fp8 form), part 0 holds the operand passes and the C entry points.  The parts build in parallel.
+// Parts 8 and 9 (the four-wave layout, with -DQT_PS_WITH_W4 on every part) are built only when QT_PS_WITH_W4 is set in the environment.
 #ifndef QT_PS_PART
 #define QT_PS_PART 0
 #endif
 // one launcher per group: (a_kslow, b_kslow, swap) and, for the short tiles, WMT select the instance
 #define QT_PS_DECL(NAME) void NAME(const PlaneArgs& a, int a_kslow, int b_kslow, int swap, int wmt, dim3 grid, hipStream_t st)
 QT_PS_DECL(qt_ps_launch_mf0_t4); QT_PS_DECL(qt_ps_launch_mf0_t32); QT_PS_DECL(qt_ps_launch_fp8); QT_PS_DECL(qt_ps_launch_mf1_t4); QT_PS_DECL(qt_ps_launch_mf1_t32);
-#define QT_PS_GO(...)                                                                                          \
+QT_PS_DECL(qt_ps_launch_mf1_w4); QT_PS_DECL(qt_ps_launch_mf1_t4_pipe); QT_PS_DECL(qt_ps_launch_mf1_w4_pipe); QT_PS_DECL(qt_ps_launch_mf1_t32_pipe);
+#define QT_PS_GO_T(THREADS, ...)                                                                               \
     do {                                                                                                      \
         auto kern = qt_gemm_ps_kernel<__VA_ARGS__>;                                                           \
         static bool attr_set = false;   /* once per instance, not per launch (and never inside a stream capture) */ \
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS_BYTES); attr_set = true; } \
-        hipLaunchKernelGGL(kern, grid, dim3(512), P_LDS_BYTES, st, a);                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), P_LDS_BYTES, st, a);                                    \
+    } while (0)
+#define QT_PS_GO(...) QT_PS_GO_T(512, __VA_ARGS__)
+#define QT_PS_GO4(...) QT_PS_GO_T(256, __VA_ARGS__, 4, 2, 1, 2)      /* four waves of 128 x 128, the 16x16x32 form */
+#define QT_PS_GO8P(...) QT_PS_GO_T(512, __VA_ARGS__, 4, 2, 1, 4, 1)  /* eight waves, late-barrier pipeline */
+#define QT_PS_GO4P(...) QT_PS_GO_T(256, __VA_ARGS__, 4, 2, 1, 2, 2)  /* four waves, late-barrier pipeline, two B fragment sets */
+#define QT_PS_ALL8(GO)                                                                                         \
+    do {                                                                                                      \
+        if (swap) { if (!a_kslow && !b_kslow) GO(false, false, true, 0); else if (!a_kslow) GO(false, true, true, 0);        \
+                    else if (!b_kslow) GO(true, false, true, 0); else GO(true, true, true, 0); }                             \
+        else      { if (!a_kslow && !b_kslow) GO(false, false, false, 0); else if (!a_kslow) GO(false, true, false, 0);      \
+                    else if (!b_kslow) GO(true, false, false, 0); else GO(true, true, false, 0); }                           \
     } while (0)
 #define QT_PS_TALL(MF_)                                                                                        \
     do {                                                                                                      \
@@ -821,6 +985,19 @@ QT_PS_DECL(qt_ps_launch_fp8) {          // (wmt carries the MFMA shape here: 1 =
 QT_PS_DECL(qt_ps_launch_mf1_t4) { QT_PS_TALL(1); }
 #elif QT_PS_PART == 5
 QT_PS_DECL(qt_ps_launch_mf1_t32) { QT_PS_SHORT(1); }
+#elif QT_PS_PART == 8
+QT_PS_DECL(qt_ps_launch_mf1_w4) { QT_PS_ALL8(QT_PS_GO4); }
+#elif QT_PS_PART == 6
+QT_PS_DECL(qt_ps_launch_mf1_t4_pipe) { QT_PS_ALL8(QT_PS_GO8P); }
+#elif QT_PS_PART == 9
+QT_PS_DECL(qt_ps_launch_mf1_w4_pipe) { QT_PS_ALL8(QT_PS_GO4P); }
+#elif QT_PS_PART == 7
+QT_PS_DECL(qt_ps_launch_mf1_t32_pipe) {      // the 192- and 128-row tiles with the late-barrier pipeline
+    if (wmt == 3) { if (swap) { if (b_kslow) QT_PS_GO(false, true, true, 0, 3, 2, 1, 4, 1); else QT_PS_GO(false, false, true, 0, 3, 2, 1, 4, 1); }
+                    else      { if (b_kslow) QT_PS_GO(false, true, false, 0, 3, 2, 1, 4, 1); else QT_PS_GO(false, false, false, 0, 3, 2, 1, 4, 1); } }
+    else          { if (swap) { if (b_kslow) QT_PS_GO(false, true, true, 0, 2, 2, 1, 4, 1); else QT_PS_GO(false, false, true, 0, 2, 2, 1, 4, 1); }
+                    else      { if (b_kslow) QT_PS_GO(false, true, false, 0, 2, 2, 1, 4, 1); else QT_PS_GO(false, false, false, 0, 2, 2, 1, 4, 1); } }
+}
 #else
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1252,11 +1429,26 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     // the same images, tools/ab_mfma_shape.py); QT_PS_MF=0 selects the 32x32x16 form (A/B runs; read per call)
     int mf = 1;
     { const char* e = getenv("QT_PS_MF"); if (e) mf = atoi(e); }
+    // wave layout of the 256-row tile: QT_PS_W4=1 selects four waves of 128 x 128 — only in a library built with -DQT_PS_WITH_W4
+    // (measured and not shipped: kernel comment "NWN")
+    int w4 = 0;
+#ifdef QT_PS_WITH_W4
+    { const char* e = getenv("QT_PS_W4"); if (e) w4 = atoi(e); }
+#endif
+    // the late-barrier pipeline (kernel comment "PIPE") by default: +1...+6 % on every shape of the path, bit-identical results
+    // (tools/ab_ps_variants.py, profiles/r03_pipe_ab.txt); QT_PS_PIPE=0 selects the barrier-first loop (A/B runs; read per call)
+    int pipe = 1;
+    { const char* e = getenv("QT_PS_PIPE"); if (e) pipe = atoi(e); }
     // the image of C rides on the 16x16x32 C^T epilogue of an unsplit launch; otherwise it is not written (return 3: the caller splits C)
     const bool img_ok = c_img && fmt == 0 && mf && swap && split_k == 1 && N % 32 == 0 && ld_img % 128 == 0 && qt_aligned16(c_img);
     a.c_img = img_ok ? (char*)c_img : nullptr; a.ld_img = ld_img;
     if (fmt == 1) qt_ps_launch_fp8(a, 0, 0, swap, mf ? 1 : 0, grid, st);
+    else if (wmt != 4 && mf && pipe) qt_ps_launch_mf1_t32_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
+#ifdef QT_PS_WITH_W4
+    else if (mf && w4) { if (pipe) qt_ps_launch_mf1_w4_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf1_w4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
+#endif
+    else if (mf && pipe) qt_ps_launch_mf1_t4_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);
     if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate, c_amax); if (rc) return rc; }
