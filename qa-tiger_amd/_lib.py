@@ -75,7 +75,7 @@ def _build_locked(srcs, verbose: bool, force: bool = False) -> str:
     jobs = []
     for src in srcs:
         base = os.path.splitext(os.path.basename(src))[0]
-        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else ((range(10 if W4 else 8), 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
+        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else ((range(12 if W4 else 10), 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
         for part in parts:
             obj = os.path.join(objdir, base + ('' if part is None else f'_p{part}') + '.o')
             jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-D{macro}={part}']), obj))

@@ -113,6 +113,7 @@ template <int N, class F> __device__ inline void p_static_for(F&& f) { p_static_
 //      the NEXT step's stages: when a step begins its first MFMA has its operands in registers, so the matrix pipe no longer idles through
 //      barrier + ~20 KiB of fragment reads per wave at every step.  Transfers run one step further ahead on the same stages (B(t+2) and
 //      A(t+3) go out right after the barrier of step t, which is also the point where every wave has finished reading B(t) and A(t)).
+//      PIPE = 3 (eight waves): the barrier in front of the last TWO segments (compute16p); the default where B is K-slow.
 //      PIPE = 2 (four-wave layout: 256 of its 512 registers hold the accumulators, ~130 are free): TWO B fragment sets — the next step's
 //      B fragments are all requested right after the barrier, in front of the last segment's MFMAs, instead of pair by pair behind them.
 template <bool AKS, bool BKS, bool SWAP, int FMT, int WMT = 4, int NWM = 2, int MF = 0, int NWN = 4, int PIPE = 0>
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                   "tile shapes: 8 waves x (128|96|64) x 64, or 16 waves x 64 x 64");
     static_assert(PIPE == 0 || (MF == 1 && FMT == 0), "the late-barrier pipeline: the fp16 16x16x32 form");
     static_assert(PIPE != 2 || NWN == 2, "two B fragment sets: only the four-wave layout has the registers");
+    static_assert(PIPE != 3 || NWN == 4, "the two-segment tail: the eight-wave layout");
     static_assert(NWN == 4 || (NWN == 2 && NWM == 2 && WMT == 4 && MF == 1 && FMT == 0), "four waves of 128 x 128: the fp16 16x16x32 form only");
     constexpr int WNT = 8 / NWN;                      // wave tile (32 WMT) x (32 WNT): WMT x WNT MFMA tiles of 32 x 32
     constexpr int BM = NWM * WMT * 32, BN = 256, GM = 4;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     };
 
     // ---- PIPE: fragments that live across K steps
-    uint4 pbh[PIPE == 2 ? 2 : 1][PIPE ? 2 * WNT : 1], pbl[PIPE == 2 ? 2 : 1][PIPE ? 2 * WNT : 1], pal[2], pah[2];
+    uint4 pbh[PIPE == 2 ? 2 : 1][PIPE ? 2 * WNT : 1], pbl[PIPE == 2 ? 2 : 1][PIPE ? 2 * WNT : 1], pal[PIPE == 3 ? 3 : 2], pah[PIPE == 3 ? 3 : 2];
     auto frag16 = [&](unsigned base, const unsigned* f, bool kslow, int t, int hl) -> uint4 {
         if (!kslow) return lds_u4(base + f[hl] + t * 2048);
         const unsigned kb = base + (unsigned)((t >> 2) * 256 + 32 * (t & 1)) + f[2 * ((t >> 1) & 1) + hl];
@@ -430,7 +432,48 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
             if (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, y), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
             else      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
         };
-        if constexpr (PIPE) {
+        if constexpr (PIPE == 3) {
+            // The barrier sits in front of the last TWO segments, which run as one: for every B pair the three MFMAs of row tile NS-2 and the
+            // three of row tile NS-1, then that pair's re-load from the next step's stage — the 2 WNT re-loads are spread over 12 WNT MFMAs
+            // instead of 6 WNT (eight waves re-loading 8 KiB each keep the LDS busy for ~500 cycles).  Both row tiles' A fragments are
+            // fetched BEFORE the barrier (a third fragment buffer), so that after it nothing reads this step's stages any more.
+            p_static_for<NS - 2>([&](auto IT) {
+                constexpr int it = decltype(IT)::value, cur = it & 1;
+                pal[cur ^ 1] = frag16(sA, fa16, AKS, it + 1, 1);
+                pah[cur ^ 1] = frag16(sA, fa16, AKS, it + 1, 0);
+                if constexpr (it == NS - 3) { pal[2] = frag16(sA, fa16, AKS, NS - 1, 1); pah[2] = frag16(sA, fa16, AKS, NS - 1, 0); }
+                issue(IT);
+                p_static_for<2 * WNT>([&](auto J) {
+                    constexpr int jt = decltype(J)::value;
+                    acc16[it][jt] = mm(pal[cur], pbh[0][jt], acc16[it][jt]);
+                    acc16[it][jt] = mm(pah[cur], pbl[0][jt], acc16[it][jt]);
+                    acc16[it][jt] = mm(pah[cur], pbh[0][jt], acc16[it][jt]);
+                });
+            });
+            // (NS is even: row tile NS-2's fragments are in buffer 0, NS-1's in buffer 2; buffer 1 is free)
+            if constexpr (has_next) {
+                sync();
+                pal[1] = frag16(sA1, fa16, AKS, 0, 1);
+                pah[1] = frag16(sA1, fa16, AKS, 0, 0);
+            }
+            issue(std::integral_constant<int, NS - 2>{});
+            p_static_for<2 * WNT>([&](auto J) {
+                constexpr int jt = decltype(J)::value;
+                if constexpr (jt == WNT) issue(std::integral_constant<int, NS - 1>{});
+                acc16[NS - 2][jt] = mm(pal[0], pbh[0][jt], acc16[NS - 2][jt]);
+                acc16[NS - 2][jt] = mm(pah[0], pbl[0][jt], acc16[NS - 2][jt]);
+                acc16[NS - 2][jt] = mm(pah[0], pbh[0][jt], acc16[NS - 2][jt]);
+                acc16[NS - 1][jt] = mm(pal[2], pbh[0][jt], acc16[NS - 1][jt]);
+                acc16[NS - 1][jt] = mm(pah[2], pbl[0][jt], acc16[NS - 1][jt]);
+                acc16[NS - 1][jt] = mm(pah[2], pbh[0][jt], acc16[NS - 1][jt]);
+                if constexpr (has_next) {
+                    pbh[0][jt] = frag16(sB1, fb16, BKS, jt, 0);
+                    pbl[0][jt] = frag16(sB1, fb16, BKS, jt, 1);
+                    __builtin_amdgcn_sched_barrier(0);               // keep each pair's re-load right behind its last readers (the scheduler otherwise gathers them in two groups)
+                }
+            });
+            if constexpr (has_next) { pal[0] = pal[1]; pah[0] = pah[1]; }      // the next step's segment 0 multiplies out of buffer 0
+        } else if constexpr (PIPE) {
             p_static_for<NS>([&](auto IT) {
                 constexpr int it = decltype(IT)::value, cur = it & 1;
                 if constexpr (it + 1 < NS) {
@@ -551,6 +594,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                     constexpr int NP = NBP + NAP;
                     p_static_for<NP>([&](auto PC) {
                         constexpr int pc = decltype(PC)::value;
+                        if constexpr (PIPE == 3) {
+                            // B(t+2) right behind the barrier (segments NS-2, NS-1) into the stage that held B(t); A(t+2) over segments 0 .. NS-3
+                            // into the stage that held A(t-1) (every wave finished reading it before the barrier of step t-1)
+                            if constexpr (pc < NBP) { if constexpr (seg == NS - 2 + (pc * 2) / NBP) { if (t + 2 < nk) dma_b1(kbeg + (t + 2) * KS, gb & 1, pc); } }
+                            else if constexpr (seg == ((pc - NBP) * (NS - 2)) / NAP) { if (t > 0 && t + 2 < nk) dma_a1(ka2, sta, pc - NBP); }
+                            return;
+                        }
                         constexpr int slot = pc < NBP ? (pc * 2) / NBP : 2 + ((pc - NBP) * (NS - 2)) / NAP;     // B first (it has one step to land), A behind it
                         if constexpr (slot == 0) {
                             if constexpr (seg == NS - 1) {           // cycle(t): B(t+2) -> the stage that held B(t), A(t+3) -> the stage that held A(t)
@@ -929,9 +979,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     }
 }
 
-// This file is compiled eight times (qa-tiger_amd/_lib.py): -DQT_PS_PART=1..7 each instantiate one group of the GEMM kernel (MFMA shape x
+// This file is compiled ten times (qa-tiger_amd/_lib.py): -DQT_PS_PART=1..9 each instantiate one group of the GEMM kernel (MFMA shape x
 // tile heights x loop form; the fp8 form), part 0 holds the operand passes and the C entry points.  The parts build in parallel.
-// Parts 8 and 9 (the four-wave layout, with -DQT_PS_WITH_W4 on every part) are built only when QT_PS_WITH_W4 is set in the environment.
+// Parts 10 and 11 (the four-wave layout, with -DQT_PS_WITH_W4 on every part) are built only when QT_PS_WITH_W4 is set in the environment.
 #ifndef QT_PS_PART
 #define QT_PS_PART 0
 #endif
@@ -939,6 +989,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
 #define QT_PS_DECL(NAME) void NAME(const PlaneArgs& a, int a_kslow, int b_kslow, int swap, int wmt, dim3 grid, hipStream_t st)
 QT_PS_DECL(qt_ps_launch_mf0_t4); QT_PS_DECL(qt_ps_launch_mf0_t32); QT_PS_DECL(qt_ps_launch_fp8); QT_PS_DECL(qt_ps_launch_mf1_t4); QT_PS_DECL(qt_ps_launch_mf1_t32);
 QT_PS_DECL(qt_ps_launch_mf1_w4); QT_PS_DECL(qt_ps_launch_mf1_t4_pipe); QT_PS_DECL(qt_ps_launch_mf1_w4_pipe); QT_PS_DECL(qt_ps_launch_mf1_t32_pipe);
+QT_PS_DECL(qt_ps_launch_mf1_t4_pipe3); QT_PS_DECL(qt_ps_launch_mf1_t32_pipe3);
 #define QT_PS_GO_T(THREADS, ...)                                                                               \
     do {                                                                                                      \
         auto kern = qt_gemm_ps_kernel<__VA_ARGS__>;                                                           \
@@ -949,6 +1000,7 @@ QT_PS_DECL(qt_ps_launch_mf1_w4); QT_PS_DECL(qt_ps_launch_mf1_t4_pipe); QT_PS_DEC
 #define QT_PS_GO(...) QT_PS_GO_T(512, __VA_ARGS__)
 #define QT_PS_GO4(...) QT_PS_GO_T(256, __VA_ARGS__, 4, 2, 1, 2)      /* four waves of 128 x 128, the 16x16x32 form */
 #define QT_PS_GO8P(...) QT_PS_GO_T(512, __VA_ARGS__, 4, 2, 1, 4, 1)  /* eight waves, late-barrier pipeline */
+#define QT_PS_GO8P3(...) QT_PS_GO_T(512, __VA_ARGS__, 4, 2, 1, 4, 3) /* eight waves, late-barrier pipeline with the two-segment tail */
 #define QT_PS_GO4P(...) QT_PS_GO_T(256, __VA_ARGS__, 4, 2, 1, 2, 2)  /* four waves, late-barrier pipeline, two B fragment sets */
 #define QT_PS_ALL8(GO)                                                                                         \
     do {                                                                                                      \
@@ -986,10 +1038,19 @@ QT_PS_DECL(qt_ps_launch_mf1_t4) { QT_PS_TALL(1); }
 #elif QT_PS_PART == 5
 QT_PS_DECL(qt_ps_launch_mf1_t32) { QT_PS_SHORT(1); }
 #elif QT_PS_PART == 8
+QT_PS_DECL(qt_ps_launch_mf1_t4_pipe3) { QT_PS_ALL8(QT_PS_GO8P3); }
+#elif QT_PS_PART == 9
+QT_PS_DECL(qt_ps_launch_mf1_t32_pipe3) {
+    if (wmt == 3) { if (swap) { if (b_kslow) QT_PS_GO(false, true, true, 0, 3, 2, 1, 4, 3); else QT_PS_GO(false, false, true, 0, 3, 2, 1, 4, 3); }
+                    else      { if (b_kslow) QT_PS_GO(false, true, false, 0, 3, 2, 1, 4, 3); else QT_PS_GO(false, false, false, 0, 3, 2, 1, 4, 3); } }
+    else          { if (swap) { if (b_kslow) QT_PS_GO(false, true, true, 0, 2, 2, 1, 4, 3); else QT_PS_GO(false, false, true, 0, 2, 2, 1, 4, 3); }
+                    else      { if (b_kslow) QT_PS_GO(false, true, false, 0, 2, 2, 1, 4, 3); else QT_PS_GO(false, false, false, 0, 2, 2, 1, 4, 3); } }
+}
+#elif QT_PS_PART == 10
 QT_PS_DECL(qt_ps_launch_mf1_w4) { QT_PS_ALL8(QT_PS_GO4); }
 #elif QT_PS_PART == 6
 QT_PS_DECL(qt_ps_launch_mf1_t4_pipe) { QT_PS_ALL8(QT_PS_GO8P); }
-#elif QT_PS_PART == 9
+#elif QT_PS_PART == 11
 QT_PS_DECL(qt_ps_launch_mf1_w4_pipe) { QT_PS_ALL8(QT_PS_GO4P); }
 #elif QT_PS_PART == 7
 QT_PS_DECL(qt_ps_launch_mf1_t32_pipe) {      // the 192- and 128-row tiles with the late-barrier pipeline
@@ -1436,18 +1497,23 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     { const char* e = getenv("QT_PS_W4"); if (e) w4 = atoi(e); }
 #endif
     // the late-barrier pipeline (kernel comment "PIPE") by default: +1...+6 % on every shape of the path, bit-identical results
-    // (tools/ab_ps_variants.py, profiles/r03_pipe_ab.txt); QT_PS_PIPE=0 selects the barrier-first loop (A/B runs; read per call)
-    int pipe = 1;
+    // (tools/ab_ps_variants.py, profiles/r03_pipe_ab.txt).  Its two-segment tail (PIPE 3) where B is K-slow (dX, dW: the transposing
+    // fragment reads are twice as many instructions, spreading them pays: +2...+4.5 % over PIPE 1), the one-segment tail (PIPE 1) where B
+    // is in row form (forward: PIPE 3 measured 1-4 % slower there).  QT_PS_PIPE=0 selects the barrier-first loop, 1 / 3 force a form
+    // (A/B runs; read per call)
+    int pipe = b_kslow ? 3 : 1;
     { const char* e = getenv("QT_PS_PIPE"); if (e) pipe = atoi(e); }
     // the image of C rides on the 16x16x32 C^T epilogue of an unsplit launch; otherwise it is not written (return 3: the caller splits C)
     const bool img_ok = c_img && fmt == 0 && mf && swap && split_k == 1 && N % 32 == 0 && ld_img % 128 == 0 && qt_aligned16(c_img);
     a.c_img = img_ok ? (char*)c_img : nullptr; a.ld_img = ld_img;
     if (fmt == 1) qt_ps_launch_fp8(a, 0, 0, swap, mf ? 1 : 0, grid, st);
+    else if (wmt != 4 && mf && pipe == 3) qt_ps_launch_mf1_t32_pipe3(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else if (wmt != 4 && mf && pipe) qt_ps_launch_mf1_t32_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
 #ifdef QT_PS_WITH_W4
     else if (mf && w4) { if (pipe) qt_ps_launch_mf1_w4_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf1_w4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
 #endif
+    else if (mf && pipe == 3) qt_ps_launch_mf1_t4_pipe3(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else if (mf && pipe) qt_ps_launch_mf1_t4_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
     QT_CHECK_LAUNCH(who);

@@ -147,9 +147,9 @@ def test_gemm_ps_both_tile_heights(ops, wmt, monkeypatch):
 @pytest.mark.parametrize('aks,bks', [(False, False), (False, True), (True, True), (True, False)])
 @pytest.mark.parametrize('wmt', [4, 3, 2])
 def test_gemm_ps_loop_forms_agree(ops, aks, bks, wmt, monkeypatch):
-    """The late-barrier pipeline (the default K loop, gemm_plane.hip "PIPE": barrier in front of a step's LAST segment, the next step's
-    fragments fetched behind it, transfers one step further ahead) against the barrier-first loop (QT_PS_PIPE=0): the same MFMAs in the
-    same order, so the products must be BIT-identical — for one, two, three and many K steps per tile, ragged tiles, several rounds of
+    """The late-barrier pipeline (the default K loop, gemm_plane.hip "PIPE": barrier in front of a step's last segment — or last two
+    segments, PIPE 3 —, the next step's fragments fetched behind it, transfers one step further ahead) against the barrier-first loop
+    (QT_PS_PIPE=0): the same MFMAs per accumulator in the same order, so the products must be BIT-identical — for one, two, three and many K steps per tile, ragged tiles, several rounds of
     the persistent tile walk (stage rotation across tiles), K splits, and both against fp64."""
     if wmt != 4 and aks:
         pytest.skip('the 192- and 128-row tiles take row-form A operands only')
@@ -158,15 +158,16 @@ def test_gemm_ps_loop_forms_agree(ops, aks, bks, wmt, monkeypatch):
         a = rnd(*((K, M) if aks else (M, K)), seed=51)
         b = rnd(*((K, N) if bks else (N, K)), seed=52)
         ia, ib = ops.split_image(a.to(DEV)), ops.split_image(b.to(DEV))
-        monkeypatch.setenv('QT_PS_PIPE', '0')
-        o0 = ops.gemm_ps(ia, ib, a_kslow=aks, b_kslow=bks, split_k=sk)
-        monkeypatch.setenv('QT_PS_PIPE', '1')
-        o1 = ops.gemm_ps(ia, ib, a_kslow=aks, b_kslow=bks, split_k=sk)
-        assert o0 is not None and o1 is not None
+        outs = {}
+        for form in ('0', '1', '3'):                      # barrier-first; late barrier with the one-segment / the two-segment tail
+            monkeypatch.setenv('QT_PS_PIPE', form)
+            outs[form] = ops.gemm_ps(ia, ib, a_kslow=aks, b_kslow=bks, split_k=sk)
+            assert outs[form] is not None
         ref = (a.double().t() if aks else a.double()) @ (b.double() if bks else b.double().t())
-        assert rel(o1, ref) < 2e-6, (M, N, K, sk)
-        if sk <= 1 or (aks and bks):                      # (K splits that meet in atomics have no fixed summation order)
-            assert torch.equal(o0, o1), (M, N, K, sk)
+        for form in ('1', '3'):
+            assert rel(outs[form], ref) < 2e-6, (M, N, K, sk, form)
+            if sk <= 1 or (aks and bks):                  # (K splits that meet in atomics have no fixed summation order)
+                assert torch.equal(outs['0'], outs[form]), (M, N, K, sk, form)
 
 
 def test_gemm_ps_records_max_of_what_it_stores(ops):
