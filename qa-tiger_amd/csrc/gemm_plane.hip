@@ -132,6 +132,17 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     constexpr int BM = NWM * WMT * 32, BN = 256, GM = 4;
     constexpr int NBP = 32 / (NWM * NWN);              // 1 KiB DMA pieces of the B tile per wave
     constexpr int NAP = 4 * WMT / NWN;                 // ... and of the A tile (BM / 8 pieces over NWM x NWN waves)
+    // A stages.  The 192- and 128-row tiles leave a quarter (half) of every 32 KiB A stage unused: at a pitch of 24 KiB the same 96 KiB
+    // hold FOUR stages (B still starts at 96 KiB) and A runs one more step ahead.  Built and measured (QT_PS_NAS4, profiles/r03_pipe_ab.txt
+    // section 9): bit-identical, no gain (30720x2304x768 0.297 ms against 0.288-0.298 with three stages) — the 11-19 % that the transfers
+    // cost a step (QT_PS_DEBUG=2 switches them off) are not latency that a deeper prefetch hides.  Off by default.
+#ifdef QT_PS_NAS4
+    constexpr int NAS = ((PIPE == 1 || PIPE == 3) && WMT < 4) ? 4 : P_A_STAGES;
+#else
+    constexpr int NAS = P_A_STAGES;
+#endif
+    constexpr unsigned A_PITCH = NAS == 4 ? 24576u : (unsigned)P_OPER;
+    static_assert(NAS * A_PITCH == P_B_BASE, "the A stages fill the LDS below the B stages");
     constexpr int NS = 2 * WMT;                       // compute segments per K step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -197,13 +208,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     // — BASELINE config 4 at B = 128 — is 6.6 GB), m0 is uniform and current whenever a DMA of this tile is issued.
     auto dma_a = [&](int k0, int stage) {
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
-        const unsigned la = lds0 + stage * P_OPER + wave * (NAP * 1024);
+        const unsigned la = lds0 + stage * A_PITCH + wave * (NAP * 1024);
 #pragma unroll
         for (int i = 0; i < NAP; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
     auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
         const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
-        qt_dma16(lds0 + stage * P_OPER + wave * (NAP * 1024) + i * 1024, sa, offA[i]);
+        qt_dma16(lds0 + stage * A_PITCH + wave * (NAP * 1024) + i * 1024, sa, offA[i]);
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
         const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
@@ -548,14 +559,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     }
     // Stages are addressed by running step counters that continue across tiles: A step g lives in stage g % 3, B step g in g & 1.
     int sa_cur = 0, gb = 0;                            // A stage of the current step; B step parity
-    auto nxt3 = [](int s) { return s == P_A_STAGES - 1 ? 0 : s + 1; };
-    auto tile_prologue = [&]() {     // !PIPE: A(0), A(1), B(0);  PIPE: A(0), B(0), A(1), B(1), A(2) — in this order (the counted waits rely on it)
+    auto nxt3 = [](int s) { return s == NAS - 1 ? 0 : s + 1; };            // (next A stage; the name is from the three-stage days)
+    auto prevA = [](int s) { return s == 0 ? NAS - 1 : s - 1; };
+    auto tile_prologue = [&]() {     // !PIPE: A(0), A(1), B(0);  PIPE: A(0), B(0), A(1), B(1), A(2) [, A(3) with four A stages] — in this order (the counted waits rely on it)
         const int nk0 = (kend - kbeg) / KS;
         if constexpr (PIPE) {
             dma_a(kbeg, sa_cur);
             dma_b(kbeg, gb & 1);
             if (nk0 > 1) { dma_a(kbeg + KS, nxt3(sa_cur)); dma_b(kbeg + KS, (gb + 1) & 1); }
             if (nk0 > 2) dma_a(kbeg + 2 * KS, nxt3(nxt3(sa_cur)));
+            if constexpr (NAS == 4) { if (nk0 > 3) dma_a(kbeg + 3 * KS, prevA(sa_cur)); }
         } else {
             dma_a(kbeg, sa_cur);
             if (nk0 > 1) dma_a(kbeg + KS, nxt3(sa_cur));
@@ -582,41 +595,41 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            first_frags((unsigned)(sa_cur * P_OPER), (unsigned)(P_B_BASE + (gb & 1) * P_OPER));
+            first_frags((unsigned)(sa_cur * A_PITCH), (unsigned)(P_B_BASE + (gb & 1) * P_OPER));
             auto step = [&](const int t, auto HAS_NEXT, auto PAR) {
-                const int kb1 = kbeg + (t + 1) * KS, ka2 = kbeg + (t + 2) * KS;
-                const int stb = (gb + 1) & 1, sta = nxt3(nxt3(sa_cur));
-                // Transfers are issued in CYCLES that open right after a step's barrier: cycle(t) = B(t+2) pieces, then A(t+3) pieces; its first
-                // slot is the last segment of step t, the others are segments 0 .. NS-2 of step t+1.  (cycle(-1) = B(1), A(2) is the prologue's.)
-                // At the barrier of step t the youngest transfers are the NAP pieces of A(t+2) (if it exists): everything older has landed.
+                constexpr int D = NAS - 1;                           // the A tile requested during step t is A(t + D); it takes the stage that held A(t-1)
+                const int kb1 = kbeg + (t + 1) * KS, ka2 = kbeg + (t + D) * KS;
+                const int stb = (gb + 1) & 1, sta = prevA(sa_cur);
+                // Transfers are issued in CYCLES that open right after a step's barrier: cycle(t) = B(t+2) pieces, then A(t+1+D) pieces; its first
+                // slot is the last segment of step t, the others are segments 0 .. NS-2 of step t+1.  (cycle(-1) = B(1), A(D) is the prologue's.)
+                // At the barrier of step t the youngest transfers are the NAP pieces of A(t+D) (if it exists): everything older has landed.
                 auto issue = [&](auto SEG) {
                     constexpr int seg = decltype(SEG)::value;
                     constexpr int NP = NBP + NAP;
+                    if (p.debug & 2) return;                         // probe: only the tile prologue's transfers (the steps multiply stale stages)
                     p_static_for<NP>([&](auto PC) {
                         constexpr int pc = decltype(PC)::value;
                         if constexpr (PIPE == 3) {
                             // B(t+2) right behind the barrier (segments NS-2, NS-1) into the stage that held B(t); A(t+2) over segments 0 .. NS-3
                             // into the stage that held A(t-1) (every wave finished reading it before the barrier of step t-1)
                             if constexpr (pc < NBP) { if constexpr (seg == NS - 2 + (pc * 2) / NBP) { if (t + 2 < nk) dma_b1(kbeg + (t + 2) * KS, gb & 1, pc); } }
-                            else if constexpr (seg == ((pc - NBP) * (NS - 2)) / NAP) { if (t > 0 && t + 2 < nk) dma_a1(ka2, sta, pc - NBP); }
+                            else if constexpr (seg == ((pc - NBP) * (NS - 2)) / NAP) { if (t > 0 && t + D < nk) dma_a1(ka2, sta, pc - NBP); }
                             return;
                         }
                         constexpr int slot = pc < NBP ? (pc * 2) / NBP : 2 + ((pc - NBP) * (NS - 2)) / NAP;     // B first (it has one step to land), A behind it
                         if constexpr (slot == 0) {
-                            if constexpr (seg == NS - 1) {           // cycle(t): B(t+2) -> the stage that held B(t), A(t+3) -> the stage that held A(t)
-                                if constexpr (pc < NBP) { if (t + 2 < nk) dma_b1(kbeg + (t + 2) * KS, gb & 1, pc); }
-                                else { if (t + 3 < nk) dma_a1(kbeg + (t + 3) * KS, sa_cur, pc - NBP); }
-                            }
-                        } else if constexpr (slot - 1 == seg) {      // cycle(t-1): B(t+1), A(t+2)
+                            static_assert(pc < NBP, "slot 0 holds B pieces only");
+                            if constexpr (seg == NS - 1) { if (t + 2 < nk) dma_b1(kbeg + (t + 2) * KS, gb & 1, pc); }      // cycle(t): B(t+2) -> the stage that held B(t)
+                        } else if constexpr (slot - 1 == seg) {      // cycle(t-1): B(t+1), A(t+D)
                             if (t > 0) {
                                 if constexpr (pc < NBP) { if (t + 1 < nk) dma_b1(kb1, stb, pc); }
-                                else { if (t + 2 < nk) dma_a1(ka2, sta, pc - NBP); }
+                                else { if (t + D < nk) dma_a1(ka2, sta, pc - NBP); }
                             }
                         }
                     });
                 };
                 auto sync = [&]() {
-                    if (t + 2 < nk) {
+                    if (t + D < nk) {                                // the youngest transfers are the NAP pieces of A(t+D); everything older — A(t+1), B(t+1) among it — has landed
                         if constexpr (NAP == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                         else if constexpr (NAP == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                         else if constexpr (NAP == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -625,7 +638,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 };
-                const unsigned sA = (unsigned)(sa_cur * P_OPER), sA1 = (unsigned)(nxt3(sa_cur) * P_OPER), sB1 = (unsigned)(P_B_BASE + ((gb + 1) & 1) * P_OPER);
+                const unsigned sA = (unsigned)(sa_cur * A_PITCH), sA1 = (unsigned)(nxt3(sa_cur) * A_PITCH), sB1 = (unsigned)(P_B_BASE + ((gb + 1) & 1) * P_OPER);
                 compute16p(HAS_NEXT, PAR, sA, sA1, sB1, issue, sync);
                 sa_cur = nxt3(sa_cur);
                 ++gb;
