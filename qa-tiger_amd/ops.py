@@ -398,6 +398,37 @@ def _carry_image(src: Tensor, dst: Tensor) -> None:
         dst._qt_img = ((dst._version, dst.data_ptr(), pass_epoch), cached[1])
 
 
+class _SplitRowsFn(torch.autograd.Function):
+    """x [2n, ...] -> (x[:n], x[n:]) as views.  Autograd's own slice backward builds, per half, a zero-filled tensor of the FULL size,
+    copies the half's gradient in and then adds the two (at the primary config, for the [2B, T, D] output of AVQCrossAttn and the
+    [2BT, D] output of PatchSelecter's MLP: two fills, two copies and an add of 94 MB each, ~0.1 ms per site); here the two gradients
+    are copied into the halves of one buffer."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, n: int):
+        ctx.n, ctx.shape = n, x.shape
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n = ctx.n
+        ref = ga if ga is not None else gb
+        gx = torch.empty(ctx.shape, device=ref.device, dtype=ref.dtype)
+        for half, g in ((gx[:n], ga), (gx[n:], gb)):
+            if g is None:
+                half.zero_()
+            else:
+                half.copy_(g)
+        return gx, None
+
+
+def split_rows(x: Tensor, n: int):
+    """(x[:n], x[n:]) whose gradients meet in one buffer (see _SplitRowsFn)."""
+    if x.requires_grad and torch.is_grad_enabled():
+        return _SplitRowsFn.apply(x, n)
+    return x[:n], x[n:]
+
+
 def reshape(x: Tensor, shape) -> Tensor:
     out = _ReshapeFn.apply(x, tuple(shape)) if x.requires_grad and torch.is_grad_enabled() else x.reshape(shape)
     _carry_image(x, out)

@@ -125,8 +125,9 @@ class AVQCrossAttn(nn.Module):
         x = ops.add_layer_norm([x, f], self.norm2.weight, self.norm2.bias, drops=[False, True], drop_p=p)
         if visualize:
             w = ops.attention_avg_weights(q, kv, qst_spec, p, qst_seed)       # [2B,T,L]: audio direction, then video
-            return x[:B], x[B:], [w[:B], w[B:]]
-        return [x[:B], x[B:]]
+            xa, xv = ops.split_rows(x, B)
+            return xa, xv, [w[:B], w[B:]]
+        return list(ops.split_rows(x, B))          # (the two halves' gradients meet in one buffer: ops._SplitRowsFn)
 
 
 class QstGrounding(nn.Module):
@@ -307,7 +308,7 @@ class PatchSelecter(nn.Module):
             o_c = ops.attention(qc, kv, AttnSpec(BT, BT, 0, H, 2, P, D, 0, 0, D, q_is=1, q_rs=BT, o_rows=2 * BT), p, nxt())
         a_c = ops.linear(o_c, self.crs_attn.out_proj.weight, self.crs_attn.out_proj.bias, drop_p=p, seed=nxt(), emit_image=True)
         m = ops.linear(ops.linear(a_c, self.mlp[0].weight, self.mlp[0].bias, relu=True, emit_image=True), self.mlp[2].weight, self.mlp[2].bias)
-        v_rel, a_rel = m[:BT], m[BT:]
+        v_rel, a_rel = ops.split_rows(m, BT)
         # return order is [audio, video] (modules.py:713-716, quirk Q5)
         return [ops.add_layer_norm([a_rel], self.anorm.weight, self.anorm.bias).reshape(B, T, D),
                 ops.add_layer_norm([v_rel], self.vnorm.weight, self.vnorm.bias).reshape(B, T, D)]
