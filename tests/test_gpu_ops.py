@@ -203,6 +203,31 @@ def test_gemm_dropout_epilogue_and_mask_grad(ops):
     assert rel(mg, g * (y > 0) / (1 - p)) < 1e-6
 
 
+def test_attention_mfma_forward_with_unaligned_output_rows(ops, qt):
+    """The MFMA forward stores four consecutive columns per lane as one float4 when the rows of `o` are 16-byte aligned; through the C ABI
+    a caller may hand it any float pointer / leading dimension: the dword-store fallback must write the same values (bit for bit)."""
+    import ctypes as C
+    lib = qt._lib.load()
+    n, H, Lq, Lk, E = 48, 8, 14, 14, 256
+    dh = E // H
+    qkv = rnd(n * Lq, 3 * E, seed=71)
+    o_al = torch.empty(n * Lq, E, device=DEV)
+    buf = torch.zeros(n * Lq * (E + 1) + 1, device=DEV)                   # rows at a pitch of E + 1 floats, starting one float in
+    o_un = buf[1:].view(n * Lq, E + 1)[:, :E]
+    f4 = 4
+    for o, ldo in ((o_al, E), (o_un, E + 1)):
+        rc = lib.qt_attn_fwd(None, C.c_void_p(qkv.data_ptr()), 3 * E, Lq, 1, C.c_void_p(qkv.data_ptr() + E * f4), 3 * E,
+                             C.c_void_p(qkv.data_ptr() + 2 * E * f4), 3 * E, Lk, C.c_void_p(o.data_ptr()), ldo, Lq, 1,
+                             n, n, 0, H, Lq, Lk, dh, 1.0 / dh ** 0.5, 0.0, C.c_ulonglong(0), None)
+        assert rc == 0, lib.qt_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(o_al, o_un.contiguous())
+    q, k, v = (t.reshape(n, Lq, H, dh).transpose(1, 2).double().cpu() for t in qkv.split(E, dim=1))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) @ v).transpose(1, 2).reshape(n * Lq, E)
+    assert rel(o_al.cpu(), ref) < 2e-6
+    assert float(buf[0]) == 0.0 and float(buf.view(-1)[1:].view(n * Lq, E + 1)[:, E].abs().max()) == 0.0      # nothing outside the rows
+
+
 @pytest.mark.parametrize('Lq,Lk,n_items,n_kv,shift', [(14, 14, 1024, 1024, 0), (60, 60, 160, 160, 80), (60, 77, 160, 80, 0)])
 def test_attention_writes_split_image_for_its_out_projection(ops, Lq, Lk, n_items, n_kv, shift):
     """`attention(..., for_linear=(n_out, k_in))`: when the out-projection that consumes the result runs on the pre-split GEMM, the MFMA
