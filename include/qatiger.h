@@ -248,6 +248,13 @@ int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, int K, floa
                const float* mask_src, long ld_mask, float mask_scale,
                float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
                float* ws, long ws_floats);
+/* `batch` independent products of one shape in ONE launch: problem z multiplies the images at A + z a_bs_bytes and B + z b_bs_bytes
+ * (strides multiples of 128) and writes C + z c_bs_floats; plain epilogue (alpha), no K split.  The H head slabs of the fold GEMMs
+ * (u[:, h, :] = q[:, h-th d_h columns] W[h-th d_h rows, :]) are one such launch: the column block of q's image and the row block of
+ * W's image of head h lie h * 4 d_h resp. h * d_h * ldb_bytes bytes further on, the slab of u h * D floats. */
+int qt_gemm_ps_batched(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                       const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                       float* C, long ldc, int batch, long a_bs_bytes, long b_bs_bytes, long c_bs_floats);
 /* qt_gemm_ps that ALSO writes C as an unscaled split image (row pitch ld_img_bytes, a multiple of 128): the operand of the Linear layer
  * that consumes C, produced by the epilogue that holds the values in registers instead of by a qt_split_f16 pass over C.  Returns 3
  * (C written, image NOT written) when the launch cannot do it (a K split, unaligned rows): the caller then splits C as usual. */

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libqatiger_hip.so')
 SOURCES = ['gemm.hip', 'gemm_split.hip', 'gemm_skinny.hip', 'gemm_plane.hip', 'attn.hip', 'xattn.hip', 'norm.hip', 'moe.hip', 'misc.hip', 'text.hip', 'softmax.hip']
 GFX = 'gfx950'
-ABI_VERSION = 211          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
+ABI_VERSION = 212          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
 W4 = bool(os.environ.get('QT_PS_WITH_W4'))      # also build gemm_plane.hip's four-wave layout (an experiment: csrc/gemm_plane.hip "NWN")
 FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result'] + (['-DQT_PS_WITH_W4'] if W4 else [])
@@ -134,6 +134,7 @@ SIGNATURES = {
     'qt_gemm_f32_ws': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _i, _l, _l, _l, _p, _l],
     'qt_gemm_x3': [_p, _i, _i, _i, _i, _i, _i, _f, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _i, _l, _l, _l, _p, _p, _p, _p, _l],
     'qt_gemm_ps': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _p, _l],
+    'qt_gemm_ps_batched': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _i, _l, _l, _l],
     'qt_gemm_ps_img': [_p, _i, _i, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i, _p, _p, _l],
     'qt_gemm_f8': [_p, _i, _i, _i, _f, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _f, _f, _u64, _i, _i],
     'qt_quant_fp8': [_p, _p, _l, _l, _i, _p, _p, _l],

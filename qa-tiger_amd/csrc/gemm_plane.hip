@@ -69,6 +69,8 @@ struct PlaneArgs {
     long ws_stride;                  // > 0: split-K through a WORKSPACE — K split z stores its partial tile (plain stores, C^T orientation) at C + z * ws_stride
                                      // (C = the workspace, ldc = N) and qt_splitk_reduce sums the slabs: no atomics, no zeroing, a fixed summation order
     int debug;                       // QT_PS_DEBUG (profiling probes only): 1 skip the write-out, 2 DMA only for the first step of a tile, 4 no MFMAs
+    int batch;                       // independent problems of one shape in one launch (the H head slabs of a fold GEMM): problem z reads A + z a_bs,
+    long a_bs, b_bs, c_bs;           // B + z b_bs (bytes) and writes C + z c_bs (floats); no K split, no epilogue operands
 };
 
 // one LDS-DMA wave instruction: 64 lanes x 16 B from (sbase + voff[lane]) to LDS bytes [lds_addr, lds_addr + 1024).
@@ -157,9 +159,16 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     const int xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
     const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const int tiles = p.tiles_m * p.tiles_n;
-    const long total = (long)tiles * p.split_k;
+    const long per_problem = (long)tiles * p.split_k;
+    const long total = per_problem * p.batch;
     int m0 = 0, n0 = 0, kbeg = 0, kend = 0, ksplit = 0;
+    const char* gA = p.A; const char* gB = p.B; float* gC = p.C;      // the current problem's operands (batch > 1: they move with the tile walk)
     auto decode = [&](long w) {
+        if (p.batch > 1) {
+            const int z = __builtin_amdgcn_readfirstlane((int)(w / per_problem));
+            w -= (long)z * per_problem;
+            gA = p.A + (long)z * p.a_bs; gB = p.B + (long)z * p.b_bs; gC = p.C + (long)z * p.c_bs;
+        }
         const int t = (int)(w % tiles);
         ksplit = (int)(w / tiles);
         const int group = t / (GM * p.tiles_n);
@@ -207,21 +216,21 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     // Row-form A: the wave-uniform base moves with the tile (per-lane offsets are 32-bit: a gradient image of 537600 x 3072
     // — BASELINE config 4 at B = 128 — is 6.6 GB), m0 is uniform and current whenever a DMA of this tile is issued.
     auto dma_a = [&](int k0, int stage) {
-        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
+        const char* sa = AKS ? gA + (long)k0 * p.lda : gA + (long)m0 * p.lda + (long)(k0 / KS) * 128;
         const unsigned la = lds0 + stage * A_PITCH + wave * (NAP * 1024);
 #pragma unroll
         for (int i = 0; i < NAP; ++i) qt_dma16(la + i * 1024, sa, offA[i]);
     };
     auto dma_a1 = [&](int k0, int stage, int i) {          // one piece
-        const char* sa = AKS ? p.A + (long)k0 * p.lda : p.A + (long)m0 * p.lda + (long)(k0 / KS) * 128;
+        const char* sa = AKS ? gA + (long)k0 * p.lda : gA + (long)m0 * p.lda + (long)(k0 / KS) * 128;
         qt_dma16(lds0 + stage * A_PITCH + wave * (NAP * 1024) + i * 1024, sa, offA[i]);
     };
     auto dma_b1 = [&](int k0, int stage, int i) {
-        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
+        const char* sb = BKS ? gB + (long)k0 * p.ldb : gB + (long)(k0 / KS) * 128;
         qt_dma16(lds0 + P_B_BASE + stage * P_OPER + wave * (NBP * 1024) + i * 1024, sb, offB[i]);
     };
     auto dma_b = [&](int k0, int stage) {
-        const char* sb = BKS ? p.B + (long)k0 * p.ldb : p.B + (long)(k0 / KS) * 128;
+        const char* sb = BKS ? gB + (long)k0 * p.ldb : gB + (long)(k0 / KS) * 128;
         const unsigned lb = lds0 + P_B_BASE + stage * P_OPER + wave * (NBP * 1024);
 #pragma unroll
         for (int i = 0; i < NBP; ++i) qt_dma16(lb + i * 1024, sb, offB[i]);
@@ -698,7 +707,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
         // ---- this tile's output coordinates, kept for the epilogue while the NEXT tile's first DMA goes out
         const int em0 = m0, en0 = n0;
         const bool first_split = (ksplit == 0);
-        float* const Cw = p.C + (long)ksplit * p.ws_stride;      // (ws_stride = 0: C itself)
+        float* const Cw = gC + (long)ksplit * p.ws_stride;       // (ws_stride = 0: C itself; gC: this tile's problem — decode() below moves it on)
+        float* const eC = gC;
         w += G;
         const bool more = w < total;
         if (more) {
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                             if (has_add) addv[e8][j] = use_add ? p.add_src[mc * p.ld_add + ncl[j]] : 0.f;
                             if (full) {
                                 mskv[e8][j] = p.mask_src ? p.mask_src[mc * p.ld_mask + ncl[j]] : 1.f;
-                                oldv[e8][j] = p.accumulate ? p.C[mc * p.ldc + ncl[j]] : 0.f;
+                                oldv[e8][j] = p.accumulate ? eC[mc * p.ldc + ncl[j]] : 0.f;
                             }
                         }
                     }
@@ -751,7 +761,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                         const int e = eh * 8 + e8;
                         const int m = mrow0 + i * 32 + (e & 3) + 8 * (e >> 2);
                         if (m < p.M) {
-                            float* crow = p.C + (long)m * p.ldc + ncol0;
+                            float* crow = eC + (long)m * p.ldc + ncol0;
                             p_static_for<WNT>([&](auto J) {
                                 constexpr int j = decltype(J)::value;
                                 if (ncol0 + j * 32 < p.N) {
@@ -862,7 +872,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                         if (has_add) addv[e][jt] = use_add ? p.add_src[mc * p.ld_add + ncl[jt]] : 0.f;
                         if (full) {
                             mskv[e][jt] = p.mask_src ? p.mask_src[mc * p.ld_mask + ncl[jt]] : 1.f;
-                            oldv[e][jt] = p.accumulate ? p.C[mc * p.ldc + ncl[jt]] : 0.f;
+                            oldv[e][jt] = p.accumulate ? eC[mc * p.ldc + ncl[jt]] : 0.f;
                         }
                     }
                 }
@@ -870,7 +880,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
                 for (int e = 0; e < 4; ++e) {
                     const int m = mr0 + it * 16 + e;
                     if (m < p.M) {
-                        float* crow = p.C + (long)m * p.ldc + nc0;
+                        float* crow = eC + (long)m * p.ldc + nc0;
                         p_static_for<2 * WNT>([&](auto J) {
                             constexpr int jt = decltype(J)::value;
                             if (nc0 + jt * 16 < p.N) {
@@ -1420,12 +1430,17 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
                       float* C, long ldc, const float* bias, const float* add_src, long ld_add, int relu,
                       const float* mask_src, long ld_mask, float mask_scale,
                       float drop_p, unsigned long long drop_seed, int accumulate, int split_k, float* c_amax,
-                      float* ws = nullptr, long ws_floats = 0, void* c_img = nullptr, long ld_img = 0) {
+                      float* ws = nullptr, long ws_floats = 0, void* c_img = nullptr, long ld_img = 0,
+                      int batch = 1, long a_bs = 0, long b_bs = 0, long c_bs = 0) {
     const int KS = fmt == 1 ? 128 : PBK;
     QT_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "%s: bad problem", who);
     QT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "%s: drop_p=%f", who, drop_p);
     QT_CHECK_ARG(ldc >= N && lda_bytes % 128 == 0 && ldb_bytes % 128 == 0 && qt_aligned16(A) && qt_aligned16(B), "%s: image pitch / alignment", who);
     QT_CHECK_ARG(fmt == 0 || (!a_kslow && !b_kslow), "%s: fp8 lines are K-contiguous only", who);
+    QT_CHECK_ARG(batch >= 1 && (batch == 1 || (!bias && !add_src && !mask_src && drop_p == 0.f && !accumulate && !c_img && !c_amax &&
+                                               a_bs % 128 == 0 && b_bs % 128 == 0 && c_bs % 4 == 0)),
+                 "%s: a batched launch takes no epilogue operands and 128-byte aligned operand strides", who);
+    if (batch > 1) split_k = 1;
     if (K % KS != 0) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: K=%d is not a multiple of %d", who, K, KS);
     if ((a_kslow && M % 32) || (b_kslow && N % 32)) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: a K-slow operand needs its width to be a multiple of 32", who);
     if (M < 256 || N < 128) QT_FAIL(QT_ERR_UNSUPPORTED, "%s: problem too small for the 256x256 tile", who);
@@ -1440,6 +1455,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     a.alpha = alpha; a.a_amax = a_amax; a.b_amax = b_amax; a.bias = bias; a.add_src = add_src; a.ld_add = ld_add; a.relu = relu;
     a.mask_src = mask_src; a.ld_mask = ld_mask; a.mask_scale = mask_scale;
     a.drop_p = drop_p; a.inv_keep = 1.0f / (1.0f - drop_p); a.drop_seed = drop_seed; a.salt = qt_salt_ptr; a.accumulate = accumulate;
+    a.batch = batch; a.a_bs = a_bs; a.b_bs = b_bs; a.c_bs = c_bs;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QT_PS_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     const bool plain_epilogue = !relu && !mask_src && drop_p == 0.f;
     QT_CHECK_ARG(split_k <= 1 || plain_epilogue, "%s: split_k>1 needs a linear epilogue", who);
@@ -1459,7 +1475,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
         for (int cand = 4; cand >= 2; --cand) {
             if (cand < 4 && !wmt3_ok) break;
             if (force_wmt >= 2 && force_wmt <= 4 && wmt3_ok && cand != force_wmt) continue;
-            const long tl = (long)((M + 64 * cand - 1) / (64 * cand)) * tiles_n;
+            const long tl = (long)((M + 64 * cand - 1) / (64 * cand)) * tiles_n * batch;
             long maxs = 1;
             if (!fixed_split && plain_epilogue && tl < 2 * slots && K >= 16 * KS) { maxs = K / (4 * KS); if (maxs > 64) maxs = 64; }
             for (long s = fixed_split ? split_k : 1; s <= (fixed_split ? split_k : maxs); ++s) {
@@ -1496,7 +1512,7 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
         hipError_t e = qt_zero_2d(C, ldc, M, N, st);
         if (e != hipSuccess) QT_FAIL(QT_ERR_RUNTIME, "%s: zeroing C: %s", who, hipGetErrorString(e));
     }
-    const long total_work = tiles * split_k;
+    const long total_work = tiles * split_k * batch;
     dim3 grid((unsigned)(total_work > slots ? slots : total_work));
     const bool swap = (split_k == 1 || use_ws) && vec_ok;
     // MFMA shape of the fp16 path: the 16x16x32 form by default (the chip holds a higher clock on it: 215040x2304x768 2.04 -> 1.88 ms on
@@ -1547,6 +1563,18 @@ extern "C" int qt_gemm_ps(void* stream, int a_kslow, int b_kslow, int M, int N, 
                           float* ws, long ws_floats) {
     return plane_gemm("qt_gemm_ps", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
                       bias, add_src, ld_add, relu, mask_src, ld_mask, mask_scale, drop_p, drop_seed, accumulate, split_k, c_amax, ws, ws_floats);
+}
+
+// `batch` independent products of ONE shape in one launch: problem z multiplies the images at A + z a_bs_bytes and B + z b_bs_bytes and
+// writes C + z c_bs_floats (plain epilogue: alpha only; no K split).  The H head slabs of a fold GEMM (u_h = q_h W_k,h: M = rows, N = D,
+// K = d_h = three K steps) are bound by writing their slabs: as one launch their 1-2 rounds of tiles each become one walk of H times as
+// many tiles, without H - 1 launch ramps and half-empty last rounds.
+extern "C" int qt_gemm_ps_batched(void* stream, int a_kslow, int b_kslow, int M, int N, int K, float alpha,
+                                  const void* A, long lda_bytes, const float* a_amax, const void* B, long ldb_bytes, const float* b_amax,
+                                  float* C, long ldc, int batch, long a_bs_bytes, long b_bs_bytes, long c_bs_floats) {
+    return plane_gemm("qt_gemm_ps_batched", 0, stream, a_kslow, b_kslow, M, N, K, alpha, A, lda_bytes, a_amax, B, ldb_bytes, b_amax, C, ldc,
+                      nullptr, nullptr, 0, 0, nullptr, 0, 1.0f, 0.f, 0ull, 0, 1, nullptr, nullptr, 0, nullptr, 0,
+                      batch, a_bs_bytes, b_bs_bytes, c_bs_floats);
 }
 
 // qt_gemm_ps that ALSO writes C as an unscaled split image (c_img, row pitch ld_img_bytes: the operand of the next Linear layer, made by

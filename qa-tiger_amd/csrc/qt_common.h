@@ -8,7 +8,7 @@
 #define QT_WAVE 64
 // ABI of the extern "C" entry points; qa-tiger_amd/_lib.py (ABI_VERSION) refuses a library that reports another value.
 // Bump on ANY change of an exported signature.
-#define QT_ABI_VERSION 211
+#define QT_ABI_VERSION 212
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));

@@ -508,6 +508,29 @@ def gemm_ps(a: SplitImage, b: SplitImage, *, a_kslow: bool = False, b_kslow: boo
     return out
 
 
+def gemm_ps_batched(a: SplitImage, b: SplitImage, out: Tensor, batch: int, a_bs_bytes: int, b_bs_bytes: int, c_bs_floats: int, *,
+                    a_kslow: bool = False, b_kslow: bool = False, alpha: float = 1.0) -> bool:
+    """`batch` products of one shape in one launch (include/qatiger.h qt_gemm_ps_batched): problem z multiplies the images `a`, `b` moved on by
+    z strides and writes `out` moved on by z * c_bs_floats.  `a`, `b`, `out` describe problem 0.  False (nothing written) when the shape
+    does not fit the kernel."""
+    M, K = (a.cols, a.rows) if a_kslow else (a.rows, a.cols)
+    N, Kb = (b.cols, b.rows) if b_kslow else (b.rows, b.cols)
+    if K != Kb:
+        raise _lib.QTError(f'gemm_ps_batched: inner dimensions differ ({K} vs {Kb})')
+    _dev(out)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    rc = _launch('gemm', 2.0 * M * N * K * batch, (M, N, K, int(a_kslow), int(b_kslow), 'ps', batch), lambda: _lib.load().qt_gemm_ps_batched(
+        _stream(), int(a_kslow), int(b_kslow), M, N, K, float(alpha),
+        _ptr(a.data), 4 * a.data.stride(0), _ptr(a.amax), _ptr(b.data), 4 * b.data.stride(0), _ptr(b.amax),
+        _ptr(out), _ld(out), int(batch), int(a_bs_bytes), int(b_bs_bytes), int(c_bs_floats)))
+    if rc == -4:
+        if timer is not None:
+            timer.records.pop()
+        return False
+    _lib.check(rc, 'qt_gemm_ps_batched')
+    return True
+
+
 def quant_fp8(x: Tensor, amax: Optional[Tensor] = None, keep: bool = False) -> SplitImage:
     """fp32 [rows, cols] -> e4m3 image (one byte per element, per-tensor power-of-two scale from max|x|): BASELINE configs[4]."""
     x = as2d(x)
@@ -1217,6 +1240,26 @@ fold_kv = True      # PatchSelecter.crs_attn (Lq=2) and TempMoE.qst_attn (Lq=1) 
 fold_slab_min_rows = 8192   # query rows from which the H head slabs of the fold GEMMs go to the pre-split kernel one launch each (below: one head-batched launch)
 
 
+head_slabs_batched = _os.environ.get('QT_HEAD_SLABS_BATCHED', '1') != '0'
+
+
+def _head_slabs(ximg: SplitImage, wimg: SplitImage, out: Tensor, M: int, dh: int, D: int, H: int) -> None:
+    """out[:, h*D:(h+1)*D] = x[:, h-th dh columns] @ W[h-th dh rows, :] for the H heads, on the pre-split kernel: A = the head's column block
+    of x's image, B = the head's row block of W's image read K-slow.  Each slab is bound by writing its [M, D] floats (K = d_h is three K
+    steps): ONE batched launch walks all H slabs' tiles (QT_HEAD_SLABS_BATCHED=0: one launch per head, round 2)."""
+    a = SplitImage(ximg.data[:, :dh], M, dh, ximg.amax)
+    b = SplitImage(wimg.data[:dh], dh, D, wimg.amax)
+    if head_slabs_batched and H > 1:
+        if not gemm_ps_batched(a, b, out[:, :D], H, 4 * dh, 4 * dh * wimg.data.stride(0), D, b_kslow=True):
+            raise _lib.QTError('qt_gemm_ps_batched refused the head slabs of the fold GEMM')
+        return
+    for h in range(H):
+        a = SplitImage(ximg.data[:, h * dh:(h + 1) * dh], M, dh, ximg.amax)
+        b = SplitImage(wimg.data[h * dh:(h + 1) * dh], dh, D, wimg.amax)
+        if gemm_ps(a, b, b_kslow=True, out=out[:, h * D:(h + 1) * D], split_k=1) is None:
+            raise _lib.QTError('qt_gemm_ps refused a head slab of the fold GEMM')
+
+
 class HeadExpandFn(torch.autograd.Function):
     """U[:, h, :] = q[:, h-th d_h slice] @ W[h-th d_h rows, :]  — q [M, H*dh], W [H*dh, D] -> U [M, H*D].
     With W = the key block of an MHA in-projection this is u_h = W_k,h^T q_h: the query moved to input space."""
@@ -1235,11 +1278,7 @@ class HeadExpandFn(torch.autograd.Function):
             wimg = weight_image(w)
             if wimg is not None:
                 qimg = input_image(q, q2)
-                for h in range(H):
-                    a = SplitImage(qimg.data[:, h * dh:(h + 1) * dh], M, dh, qimg.amax)
-                    b = SplitImage(wimg.data[h * dh:(h + 1) * dh], dh, D, wimg.amax)
-                    if gemm_ps(a, b, b_kslow=True, out=u[:, h * D:(h + 1) * D], split_k=1) is None:
-                        raise _lib.QTError('qt_gemm_ps refused a head slab of the fold GEMM')
+                _head_slabs(qimg, wimg, u, M, dh, D, H)
                 done = True
         if not done:
             gemm(q2[:, :dh], w2[:dh], trans_b=False, out=u[:, :D], batch=(H, dh, dh * D, D), mode=precision['fwd'])
@@ -1306,11 +1345,7 @@ class HeadContractFn(torch.autograd.Function):
                 wimg = weight_image(ctx_.w_obj)
                 if wimg is not None:                    # same slab structure as HeadExpandFn.forward: dC_h = dO_h W_v,h
                     gimg = split_image(do, amax=gam)
-                    for h in range(H):
-                        a = SplitImage(gimg.data[:, h * dh:(h + 1) * dh], M, dh, gam)
-                        b = SplitImage(wimg.data[h * dh:(h + 1) * dh], dh, D, wimg.amax)
-                        if gemm_ps(a, b, b_kslow=True, out=dc[:, h * D:(h + 1) * D], split_k=1) is None:
-                            raise _lib.QTError('qt_gemm_ps refused a head slab of the fold GEMM')
+                    _head_slabs(SplitImage(gimg.data, M, H * dh, gam), wimg, dc, M, dh, D, H)
                     done = True
             if not done:
                 gemm(do[:, :dh], w2[:dh], trans_b=False, out=dc[:, :D], batch=(H, dh, dh * D, D), mode=precision['bwd'], a_amax=gam)

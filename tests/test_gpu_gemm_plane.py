@@ -170,6 +170,26 @@ def test_gemm_ps_loop_forms_agree(ops, aks, bks, wmt, monkeypatch):
                 assert torch.equal(outs['0'], outs[form]), (M, N, K, sk, form)
 
 
+def test_gemm_ps_batched_equals_one_launch_per_problem(ops):
+    """qt_gemm_ps_batched: the H head slabs of a fold GEMM (column block h of x's image times row block h of W's image, K = d_h = three
+    K steps, K-slow B) as ONE launch — bit-identical to one qt_gemm_ps launch per head, several rounds of the persistent walk."""
+    M, H, dh, D = 2112, 8, 96, 768
+    x, w = rnd(M, H * dh, seed=61), rnd(H * dh, D, seed=62, scale=0.05)
+    xi, wi = ops.split_image(x.to(DEV)), ops.split_image(w.to(DEV), scaled=True)
+    one = torch.empty(M, H * D, device=DEV)
+    for h in range(H):
+        a = ops.SplitImage(xi.data[:, h * dh:(h + 1) * dh], M, dh, xi.amax)
+        b = ops.SplitImage(wi.data[h * dh:(h + 1) * dh], dh, D, wi.amax)
+        assert ops.gemm_ps(a, b, b_kslow=True, out=one[:, h * D:(h + 1) * D], split_k=1) is not None
+    bat = torch.full((M, H * D), float('nan'), device=DEV)
+    a = ops.SplitImage(xi.data[:, :dh], M, dh, xi.amax)
+    b = ops.SplitImage(wi.data[:dh], dh, D, wi.amax)
+    assert ops.gemm_ps_batched(a, b, bat[:, :D], H, 4 * dh, 4 * dh * wi.data.stride(0), D, b_kslow=True)
+    assert torch.equal(one, bat)
+    ref = torch.einsum('mhk,hkd->mhd', x.double().view(M, H, dh), w.double().view(H, dh, D)).reshape(M, H * D)
+    assert rel(bat, ref) < 2e-6
+
+
 def test_gemm_ps_records_max_of_what_it_stores(ops):
     """c_amax: the epilogue folds max|C| of the values AS STORED (bias, ReLU, accumulate included) into the caller's record; a
     split-K launch cannot (partial sums) and leaves the tensor untagged."""
