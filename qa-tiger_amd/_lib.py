@@ -20,7 +20,8 @@ GFX = 'gfx950'
 ABI_VERSION = 212          # must equal QT_ABI_VERSION in csrc/qt_common.h (returned by qt_version()); bump on ANY signature change
 HASH_PATH = LIB_PATH + '.srchash'
 W4 = bool(os.environ.get('QT_PS_WITH_W4'))      # also build gemm_plane.hip's four-wave layout (an experiment: csrc/gemm_plane.hip "NWN")
-FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result'] + (['-DQT_PS_WITH_W4'] if W4 else [])
+MF0 = bool(os.environ.get('QT_PS_WITH_MF0'))    # also build its round-2 MFMA shape (QT_PS_MF=0: A/B runs)
+FLAGS = ['-O3', f'--offload-arch={GFX}', '-fPIC', '-std=c++17', '-Wno-unused-result'] + (['-DQT_PS_WITH_W4'] if W4 else []) + (['-DQT_PS_WITH_MF0'] if MF0 else [])
 
 
 class QTError(RuntimeError):
@@ -75,7 +76,7 @@ def _build_locked(srcs, verbose: bool, force: bool = False) -> str:
     jobs = []
     for src in srcs:
         base = os.path.splitext(os.path.basename(src))[0]
-        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else ((range(12 if W4 else 10), 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
+        parts, macro = (range(7), 'QT_X3_PART') if base == 'gemm_split' else (([p for p in range(12) if (p not in (1, 2) or MF0) and (p < 10 or W4)], 'QT_PS_PART') if base == 'gemm_plane' else ([None], ''))
         for part in parts:
             obj = os.path.join(objdir, base + ('' if part is None else f'_p{part}') + '.o')
             jobs.append(([hipcc, *flags, '-c', src, '-o', obj] + ([] if part is None else [f'-D{macro}={part}']), obj))

@@ -1002,9 +1002,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     }
 }
 
-// This file is compiled ten times (qa-tiger_amd/_lib.py): -DQT_PS_PART=1..9 each instantiate one group of the GEMM kernel (MFMA shape x
-// tile heights x loop form; the fp8 form), part 0 holds the operand passes and the C entry points.  The parts build in parallel.
-// Parts 10 and 11 (the four-wave layout, with -DQT_PS_WITH_W4 on every part) are built only when QT_PS_WITH_W4 is set in the environment.
+// This file is compiled eight times (qa-tiger_amd/_lib.py): -DQT_PS_PART=3..9 each instantiate one group of the GEMM kernel (tile heights
+// x loop form; the fp8 form), part 0 holds the operand passes and the C entry points.  The parts build in parallel.
+// Parts 1 and 2 (round 2's 32x32x16 MFMA shape: QT_PS_MF=0, with -DQT_PS_WITH_MF0 on every part) and parts 10 and 11 (the four-wave layout,
+// -DQT_PS_WITH_W4) are built only when QT_PS_WITH_MF0 / QT_PS_WITH_W4 is set in the environment: measured alternatives, kept for A/B runs.
 #ifndef QT_PS_PART
 #define QT_PS_PART 0
 #endif
@@ -1518,7 +1519,9 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     // MFMA shape of the fp16 path: the 16x16x32 form by default (the chip holds a higher clock on it: 215040x2304x768 2.04 -> 1.88 ms on
     // the same images, tools/ab_mfma_shape.py); QT_PS_MF=0 selects the 32x32x16 form (A/B runs; read per call)
     int mf = 1;
+#ifdef QT_PS_WITH_MF0                                   // (the 32x32x16 instances, parts 1 and 2, are built only with QT_PS_WITH_MF0 in the environment)
     { const char* e = getenv("QT_PS_MF"); if (e) mf = atoi(e); }
+#endif
     // wave layout of the 256-row tile: QT_PS_W4=1 selects four waves of 128 x 128 — only in a library built with -DQT_PS_WITH_W4
     // (measured and not shipped: kernel comment "NWN")
     int w4 = 0;
@@ -1538,13 +1541,17 @@ static int plane_gemm(const char* who, int fmt, void* stream, int a_kslow, int b
     if (fmt == 1) qt_ps_launch_fp8(a, 0, 0, swap, mf ? 1 : 0, grid, st);
     else if (wmt != 4 && mf && pipe == 3) qt_ps_launch_mf1_t32_pipe3(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else if (wmt != 4 && mf && pipe) qt_ps_launch_mf1_t32_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st);
-    else if (wmt != 4) { if (mf) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st); }
+#ifdef QT_PS_WITH_MF0
+    else if (wmt != 4 && !mf) qt_ps_launch_mf0_t32(a, a_kslow, b_kslow, swap, wmt, grid, st);
+    else if (!mf) qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st);
+#endif
+    else if (wmt != 4) qt_ps_launch_mf1_t32(a, a_kslow, b_kslow, swap, wmt, grid, st);
 #ifdef QT_PS_WITH_W4
     else if (mf && w4) { if (pipe) qt_ps_launch_mf1_w4_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf1_w4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
 #endif
     else if (mf && pipe == 3) qt_ps_launch_mf1_t4_pipe3(a, a_kslow, b_kslow, swap, wmt, grid, st);
     else if (mf && pipe) qt_ps_launch_mf1_t4_pipe(a, a_kslow, b_kslow, swap, wmt, grid, st);
-    else { if (mf) qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); else qt_ps_launch_mf0_t4(a, a_kslow, b_kslow, swap, wmt, grid, st); }
+    else qt_ps_launch_mf1_t4(a, a_kslow, b_kslow, swap, wmt, grid, st);
     QT_CHECK_LAUNCH(who);
     if (use_ws) { const int rc = qt_splitk_reduce(stream, ws, split_k, M, N, C, ldc, accumulate, c_amax); if (rc) return rc; }
     if (c_img && !img_ok) return 3;

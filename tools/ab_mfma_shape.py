@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of qt_gemm_ps's two MFMA shapes on the SAME images: v_mfma_f32_32x32x16_f16 (QT_PS_MF=0) against v_mfma_f32_16x16x32_f16
 (QT_PS_MF=1, the default), interleaved rounds in one process, HIP events, random data (MI355X_MICROARCH.md "DVFS give-back" item 7: the clock the chip
-holds under a matrix-dense load depends on the shape).  Also checks that both forms give the same product.   python tools/ab_mfma_shape.py [rounds]"""
+holds under a matrix-dense load depends on the shape).  Also checks that both forms give the same product.   python tools/ab_mfma_shape.py [rounds]
+Needs a library built with QT_PS_WITH_MF0=1 in the environment (the 32x32x16 instances are not part of the default build any more)."""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
