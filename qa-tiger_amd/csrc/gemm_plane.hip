@@ -562,6 +562,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void qt_gemm_ps_kernel(PlaneArgs p)
     if (w >= total) return;
     decode(w);
     set_offsets();
+    if ((p.debug & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);     // probe: static priority for the second-dispatched half (MI355X_MICROARCH.md "Two waves per SIMD" item 4)
     if (p.debug & 8) {                                 // probe: de-synchronise the CUs' tile phases (write-out bursts, DMA bursts)
         const int d = (int)((blockIdx.x >> 3) & 7) * ((kend - kbeg) / KS);
         for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(6);       // ~384 cycles x K steps x (0..7) = 0..7/8 of a tile
