@@ -422,6 +422,36 @@ class _SplitRowsFn(torch.autograd.Function):
         return gx, None
 
 
+class _JoinRowsFn(torch.autograd.Function):
+    """(a [n, ...], b [m, ...]) -> their concatenation along dim 0 WITHOUT a copy when b starts where a ends in the same storage (the two
+    halves `split_rows` made of one tensor, or two LayerNorm outputs written into the halves of one buffer: add_layer_norm(out=));
+    torch.cat otherwise.  Backward hands each input its rows of the gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor):
+        ctx.n = a.shape[0]
+        if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:]
+                and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                and b.storage_offset() == a.storage_offset() + a.numel()):
+            return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+        return torch.cat([a, b], dim=0)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return g[:ctx.n], g[ctx.n:]
+
+
+def join_rows(a: Tensor, b: Tensor) -> Tensor:
+    """cat([a, b], dim=0), free when the two already lie back to back in one storage (see _JoinRowsFn)."""
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        return _JoinRowsFn.apply(a, b)
+    return _JoinRowsFn.forward(_NoCtx(), a, b)
+
+
+class _NoCtx:
+    pass
+
+
 def split_rows(x: Tensor, n: int):
     """(x[:n], x[n:]) whose gradients meet in one buffer (see _SplitRowsFn)."""
     if x.requires_grad and torch.is_grad_enabled():
@@ -1472,7 +1502,7 @@ def _host_arrays(n, ptrs, lds, scales, drops, sds):
 
 class AddLayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gamma: Tensor, beta: Tensor, relu_out: bool, drop_p: float, scales, drops, sds, *xs: Tensor):
+    def forward(ctx, gamma: Tensor, beta: Tensor, relu_out: bool, drop_p: float, scales, drops, sds, out, *xs: Tensor):
         n = len(xs)
         x2 = [as2d(x) for x in xs]
         _dev(gamma, beta, *x2)
@@ -1480,7 +1510,12 @@ class AddLayerNormFn(torch.autograd.Function):
         rows, D = x2[0].shape
         for x in x2:
             assert x.shape == (rows, D)
-        y = torch.empty((rows, D), device=x2[0].device, dtype=torch.float32)
+        if out is not None:
+            out = out[0]
+            assert out.is_contiguous() and out.numel() == rows * D and out.dtype == torch.float32 and out.device == x2[0].device
+            y = out.view(rows, D)
+        else:
+            y = torch.empty((rows, D), device=x2[0].device, dtype=torch.float32)
         xhat = torch.empty_like(y)
         rstd = torch.empty((rows,), device=y.device, dtype=torch.float32)
         P, L, S, Dr, Sd = _host_arrays(n, [x.data_ptr() for x in x2], [_ld(x) for x in x2], scales, [int(d) for d in drops], sds)
@@ -1502,7 +1537,7 @@ class AddLayerNormFn(torch.autograd.Function):
         if relu_out:
             g = mask_grad(g, y, 0.0, 0)
         rows, D = xhat.shape
-        dxs = [torch.empty((rows, D), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[7 + i] else None
+        dxs = [torch.empty((rows, D), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[8 + i] else None
                for i in range(n)]
         acc_params = 0
         ggv = bgv = None
@@ -1537,16 +1572,17 @@ class AddLayerNormFn(torch.autograd.Function):
                 sk.buf, sk.holder = d, o_
         if acc_params:
             dgamma, dbeta = _grad_written(ctx.params[0], ggv), _grad_written(ctx.params[1], bgv)
-        return (dgamma, dbeta, None, None, None, None, None, *outs)
+        return (dgamma, dbeta, None, None, None, None, None, None, *outs)
 
 
 def add_layer_norm(xs: Sequence[Tensor], gamma: Tensor, beta: Tensor, scales: Optional[Sequence[float]] = None,
-                   drops: Optional[Sequence[bool]] = None, drop_p: float = 0.0, relu_out: bool = False) -> Tensor:
+                   drops: Optional[Sequence[bool]] = None, drop_p: float = 0.0, relu_out: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """out (optional): a contiguous [rows, D] buffer (e.g. one half of a larger one: see join_rows) that receives the result."""
     n = len(xs)
     scales = [1.0] * n if scales is None else list(scales)
     drops = [False] * n if drops is None else list(drops)
     sds = [seeds.next() if (d and drop_p > 0.0) else 0 for d in drops]
-    return AddLayerNormFn.apply(gamma, beta, relu_out, drop_p, scales, drops, sds, *xs)
+    return AddLayerNormFn.apply(gamma, beta, relu_out, drop_p, scales, drops, sds, None if out is None else (out,), *xs)      # (boxed: a plain buffer, not an autograd input)
 
 
 # --------------------------------------------------------------------------- #

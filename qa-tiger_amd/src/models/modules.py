@@ -259,7 +259,9 @@ class TempMoE(nn.Module):
         d2 = data.reshape(B * T, D)
         if sub_data is not None:
             S = len(sub_data)
-            xe = _AddRowsFn.apply(d2, torch.cat([s.reshape(B * T, D) for s in sub_data], dim=0))     # [S*BT, D]
+            sub2 = [s.reshape(B * T, D) for s in sub_data]
+            stacked = ops.join_rows(sub2[0], sub2[1]) if S == 2 else torch.cat(sub2, dim=0)
+            xe = _AddRowsFn.apply(d2, stacked)                                                        # [S*BT, D]
         else:
             S, xe = 1, d2
         hh = ops.linear(xe, w1, b1, relu=True, grad_premasked=True)       # [S*BT, K*Dh]
@@ -310,5 +312,7 @@ class PatchSelecter(nn.Module):
         m = ops.linear(ops.linear(a_c, self.mlp[0].weight, self.mlp[0].bias, relu=True, emit_image=True), self.mlp[2].weight, self.mlp[2].bias)
         v_rel, a_rel = ops.split_rows(m, BT)
         # return order is [audio, video] (modules.py:713-716, quirk Q5)
-        return [ops.add_layer_norm([a_rel], self.anorm.weight, self.anorm.bias).reshape(B, T, D),
-                ops.add_layer_norm([v_rel], self.vnorm.weight, self.vnorm.bias).reshape(B, T, D)]
+        # (the two results go into the halves of one buffer: vt_aggregator reads them stacked, ops.join_rows then costs nothing)
+        both = torch.empty((2, BT, D), device=m.device, dtype=torch.float32)
+        return [ops.add_layer_norm([a_rel], self.anorm.weight, self.anorm.bias, out=both[0]).reshape(B, T, D),
+                ops.add_layer_norm([v_rel], self.vnorm.weight, self.vnorm.bias, out=both[1]).reshape(B, T, D)]
